@@ -1,0 +1,144 @@
+"""adi3d_hip_cyl -- MI355X drop-in for the reference's cylindrical backend `adi3d_cyl_phi_v3`.
+
+Operator surface of adi3d_cyl_phi_v3.py:33-68, :332-350:
+    GridCyl, Material, Params, RobinR, ZBC, adi_step(Tn, grid, mat, prm, robin_r, zbc, S=None, theta=None)
+plus adi_step_masked (quick_spiral_deposition_gif_v5.py:31-70).
+
+Only the backward-Euler scheme is served: the reference's scheme="douglas" branch reads
+uninitialised memory and omits the diffusivity, so there is nothing valid to match;
+requesting it raises NotImplementedError instead of silently computing something else.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+from .adi3d_hip_coeff import DeviceField, to_device, _device, _stream, _p, _upload, _wrap
+
+__all__ = ['GridCyl', 'Material', 'Params', 'RobinR', 'ZBC', 'adi_step', 'adi_step_masked', 'DeviceField', 'to_device']
+
+
+class GridCyl:  # adi3d_cyl_phi_v3.py:33-43
+    def __init__(self, nr, nphi, nz, dr, dphi, dz, R):
+        self.nr = int(nr); self.nphi = int(nphi); self.nz = int(nz)
+        self.dr = float(dr); self.dphi = float(dphi); self.dz = float(dz)
+        self.R = float(R)
+        self.r = (np.arange(self.nr, dtype=np.float64) + 0.5) * self.dr
+        self.r_imh = self.r - 0.5 * self.dr
+        self.r_iph = self.r + 0.5 * self.dr
+        self.r_outer_face = self.r_iph[-1]
+        self._plans = {}
+        self._scratch = None
+
+    @property
+    def shape(self):
+        return (self.nr, self.nphi, self.nz)
+
+    def scratch(self):
+        if self._scratch is None or self._scratch[0].device != _device():
+            self._scratch = [torch.empty(self.shape, dtype=torch.float64, device=_device()) for _ in range(2)]
+        return self._scratch
+
+
+class Material:  # :45-50
+    def __init__(self, rho, cp, k):
+        self.rho = float(rho); self.cp = float(cp); self.k = float(k)
+
+    @property
+    def alpha(self):
+        return self.k / (self.rho * self.cp)
+
+
+class Params:  # :52-54
+    def __init__(self, dt, theta=0.5, scheme="be"):
+        self.dt = float(dt); self.theta = float(theta); self.scheme = str(scheme).lower()
+
+
+class RobinR:  # :56-58
+    def __init__(self, h, T_inf):
+        self.h = float(h); self.T_inf = float(T_inf)
+
+
+class ZBC:  # :60-68
+    def __init__(self, kind_bot='neumann0', kind_top='robin', h_bot=0.0, h_top=0.0,
+                 T_inf_bot=20.0, T_inf_top=20.0, T_bot=20.0, T_top=20.0):
+        self.kind_bot = kind_bot; self.kind_top = kind_top
+        self.h_bot = float(h_bot); self.h_top = float(h_top)
+        self.T_inf_bot = float(T_inf_bot); self.T_inf_top = float(T_inf_top)
+        self.T_bot = float(T_bot); self.T_top = float(T_top)
+
+
+class _Plan:
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            lib.adi_cyl_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def _plan(grid, mat, dt, robin_r, zbc):
+    if zbc.kind_bot not in _lib.ZBC_KINDS:
+        raise ValueError("unknown zbc.kind_bot")     # adi3d_cyl_phi_v3.py:283
+    if zbc.kind_top not in _lib.ZBC_KINDS:
+        raise ValueError("unknown zbc.kind_top")     # :296
+    key = (torch.cuda.current_device(), grid.dr, grid.dphi, grid.dz, mat.rho, mat.cp, mat.k, dt, robin_r.h,
+           robin_r.T_inf, zbc.kind_bot, zbc.kind_top, zbc.h_bot, zbc.h_top, zbc.T_inf_bot, zbc.T_inf_top,
+           zbc.T_bot, zbc.T_top)
+    pl = grid._plans.get(key)
+    if pl is None:
+        _device()
+        h = ctypes.c_void_p()
+        check(lib.adi_cyl_plan_create(grid.nr, grid.nphi, grid.nz, grid.dr, grid.dphi, grid.dz, mat.rho, mat.cp,
+                                      mat.k, dt, robin_r.h, robin_r.T_inf, _lib.ZBC_KINDS[zbc.kind_bot],
+                                      _lib.ZBC_KINDS[zbc.kind_top], zbc.h_bot, zbc.h_top, zbc.T_inf_bot,
+                                      zbc.T_inf_top, zbc.T_bot, zbc.T_top, ctypes.byref(h)))
+        pl = _Plan(h)
+        if len(grid._plans) > 16:      # drivers vary dt between segments; keep the cache bounded
+            grid._plans.clear()
+        grid._plans[key] = pl
+    return pl
+
+
+def _state(Tn, grid):
+    if isinstance(Tn, DeviceField):
+        t, kind = Tn.t, 'field'
+    elif isinstance(Tn, torch.Tensor):
+        t, kind = Tn.to(device=_device(), dtype=torch.float64).contiguous(), 'torch'
+    else:
+        t, kind = _upload(np.asarray(Tn), torch.float64), 'numpy'
+    assert tuple(t.shape) == grid.shape
+    return t, kind
+
+
+def _run(Tn, grid, mat, prm, robin_r, zbc, S, active, T_void, T_inner):
+    if prm.scheme != "be":
+        raise NotImplementedError("adi3d_hip_cyl serves scheme='be' only: the reference's 'douglas' branch "
+                                  "is numerically broken (reads uninitialised memory), so it has no valid oracle")
+    t, kind = _state(Tn, grid)
+    pl = _plan(grid, mat, prm.dt, robin_r, zbc)
+    ta, tb = grid.scratch()
+    out = torch.empty_like(t)
+    d_S = None if S is None else _upload(S, torch.float64)
+    d_act = None if active is None else _upload(active, torch.uint8)
+    check(lib.adi_cyl_step(pl.handle, _p(t), _p(out), _p(ta), _p(tb), _p(d_S), _p(d_act),
+                           float(T_void), float(T_inner), _stream()))
+    return _wrap(out, kind)
+
+
+def adi_step(Tn, grid, mat, prm, robin_r, zbc, S=None, theta=None):
+    """adi3d_cyl_phi_v3.py:332-350 (BE branch: r -> phi -> z with theta = 1; `theta` is unused there too)."""
+    return _run(Tn, grid, mat, prm, robin_r, zbc, S, None, 0.0, 0.0)
+
+
+def adi_step_masked(Tn, grid, mat, prm, robin_outer, zbc, active, robin_inner=None, robin_void=None):
+    """quick_spiral_deposition_gif_v5.py:31-70: void cells clamped to robin_void.T_inf before and after
+    the step, inactive axis-row cells to robin_inner.T_inf; the clamps are fused into the r-sweep load
+    and the z-sweep store."""
+    robin_inner = robin_inner or robin_outer
+    robin_void = robin_void or robin_outer
+    return _run(Tn, grid, mat, prm, robin_outer, zbc, None, active, robin_void.T_inf, robin_inner.T_inf)

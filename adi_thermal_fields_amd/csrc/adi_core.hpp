@@ -1,0 +1,150 @@
+// adi_core.hpp -- device-side tridiagonal machinery shared by every sweep kernel (gfx950, wave64).
+//
+// Algorithm (one tridiagonal system per grid line; replaces thomas_solve,
+// adi3d_numba_coeff.py:121-130 / _thomas_batch_axis0, adi3d_gpu_coeff.py:140-152):
+//
+//   A line of n rows is cut into Lp segments of M consecutive rows; one thread owns one segment
+//   and keeps its rows in registers.  Row M-1 of a segment is its SEPARATOR, rows 0..M-2 are
+//   INTERIOR rows.
+//     phase 1  condense():   two O(M) recurrences (top-down and bottom-up elimination of the
+//                            interior block) give the first/last interior unknown as an affine
+//                            function of the two neighbouring separators;
+//     phase 2  pcr_solve():  the Lp separators of a line form a tridiagonal system that is solved
+//                            by parallel cyclic reduction across Lp lanes of one wave (log2 Lp
+//                            steps of cross-lane shuffles, no LDS);
+//     phase 3  back_solve(): with both neighbouring separators known, the interior block is
+//                            solved from the stored inverse pivots.
+//   Every input row is read from HBM once and every output row written once; nothing is spilled.
+//   The systems are strictly diagonally dominant (b >= 1 + |a| + |c|), for which both the block
+//   elimination and PCR are unconditionally stable without pivoting.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace adi {
+
+// 1/x for x >= 1 (pivots of a diagonally dominant system): v_rcp_f64 + two Newton steps.
+// ~1 ulp; no denormal/inf handling needed in this range.
+__device__ __forceinline__ double frcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
+// Affine description of a segment's interior block seen from its two separators:
+//   x_first = gF - aF * xL - cF * xS        x_last = gL - aL * xL - cL * xS
+// (xL = separator of the previous segment, xS = own separator).
+struct Cond {
+    double gF, aF, cF, gL, aL, cL;
+};
+
+// phase 1.  a,b,c,d: the M rows (row M-1 = separator, untouched here).  ip: inverse pivots of the
+// top-down factorisation of the interior block, kept for phase 3.
+template <int M>
+__device__ __forceinline__ void condense(const double (&a)[M], const double (&b)[M], const double (&c)[M],
+                                         const double (&d)[M], double (&ip)[M - 1], Cond &k)
+{
+    constexpr int MI = M - 1;
+    double y = d[0], e = 1.0;
+    ip[0] = frcp(b[0]);
+#pragma unroll
+    for (int r = 1; r < MI; ++r) {
+        const double w = a[r] * ip[r - 1];
+        ip[r] = frcp(__builtin_fma(-w, c[r - 1], b[r]));
+        y = __builtin_fma(-w, y, d[r]);
+        e = -w * e;
+    }
+    k.gL = y * ip[MI - 1];
+    k.aL = a[0] * (e * ip[MI - 1]);
+    k.cL = c[MI - 1] * ip[MI - 1];
+
+    double jp = frcp(b[MI - 1]);
+    double z = d[MI - 1], f = 1.0;
+#pragma unroll
+    for (int r = MI - 2; r >= 0; --r) {
+        const double w = c[r] * jp;
+        jp = frcp(__builtin_fma(-w, a[r + 1], b[r]));
+        z = __builtin_fma(-w, z, d[r]);
+        f = -w * f;
+    }
+    k.gF = z * jp;
+    k.aF = a[0] * jp;
+    k.cF = c[MI - 1] * (f * jp);
+}
+
+// Reduced (separator) row of a segment from its own condensation `k` and the first-row data
+// (gFn, aFn, cFn) of the NEXT segment of the same line (ignored when cS == 0).
+__device__ __forceinline__ void reduced_row(double aS, double bS, double cS, double dS, const Cond &k,
+                                            double gFn, double aFn, double cFn,
+                                            double &ra, double &rb, double &rc, double &rd)
+{
+    ra = -aS * k.aL;
+    rb = __builtin_fma(-cS, aFn, __builtin_fma(-aS, k.cL, bS));
+    rc = -cS * cFn;
+    rd = __builtin_fma(-cS, gFn, __builtin_fma(-aS, k.gL, dS));
+}
+
+// phase 2.  Parallel cyclic reduction over the Lp separators of a line held by Lp consecutive lanes
+// (Lp a power of two <= 64, li = lane index inside the line).  Rows outside [0, Lp) are identity.
+__device__ __forceinline__ double pcr_solve(double ra, double rb, double rc, double rd, int li, int Lp)
+{
+    for (int dl = 1; dl < Lp; dl <<= 1) {
+        const double inv = frcp(rb);
+        const bool hl = (li - dl) >= 0, hh = (li + dl) < Lp;
+        const double a_lo = __shfl_up(ra, dl, Lp), c_lo = __shfl_up(rc, dl, Lp);
+        const double d_lo = __shfl_up(rd, dl, Lp), i_lo = __shfl_up(inv, dl, Lp);
+        const double a_hi = __shfl_down(ra, dl, Lp), c_hi = __shfl_down(rc, dl, Lp);
+        const double d_hi = __shfl_down(rd, dl, Lp), i_hi = __shfl_down(inv, dl, Lp);
+        const double k1 = hl ? ra * i_lo : 0.0;
+        const double k2 = hh ? rc * i_hi : 0.0;
+        rb = __builtin_fma(-k2, a_hi, __builtin_fma(-k1, c_lo, rb));
+        rd = __builtin_fma(-k2, d_hi, __builtin_fma(-k1, d_lo, rd));
+        ra = -k1 * a_lo;
+        rc = -k2 * c_hi;
+    }
+    return rd * frcp(rb);
+}
+
+// phase 3.  x[M-1] = xS; interior rows from the stored inverse pivots.
+template <int M>
+__device__ __forceinline__ void back_solve(const double (&a)[M], const double (&c)[M], const double (&d)[M],
+                                           const double (&ip)[M - 1], double xL, double xS, double (&x)[M])
+{
+    constexpr int MI = M - 1;
+    double y[MI];
+    y[0] = __builtin_fma(-a[0], xL, d[0]);
+#pragma unroll
+    for (int r = 1; r < MI; ++r) {
+        const double w = a[r] * ip[r - 1];
+        y[r] = __builtin_fma(-w, y[r - 1], d[r]);
+    }
+    y[MI - 1] = __builtin_fma(-c[MI - 1], xS, y[MI - 1]);
+    x[MI - 1] = y[MI - 1] * ip[MI - 1];
+#pragma unroll
+    for (int r = MI - 2; r >= 0; --r) x[r] = __builtin_fma(-c[r], x[r + 1], y[r]) * ip[r];
+    x[M - 1] = xS;
+}
+
+// Bijective XCD-aware block remap: blocks b, b+8, b+16, ... are observed to share an XCD (and its
+// L2); give each XCD a contiguous chunk of the tile range so neighbouring tiles hit the same L2.
+// Placement only changes speed, never results.
+__device__ __forceinline__ long xcd_chunk_tile(long b, long ntiles)
+{
+    const long q = ntiles >> 3, rem = ntiles & 7;
+    const long x = b & 7, idx = b >> 3;
+    return x * q + (x < rem ? x : rem) + idx;
+}
+
+// smallest power of two >= v (host + device)
+__host__ __device__ inline int next_pow2(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+}  // namespace adi

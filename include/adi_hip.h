@@ -1,0 +1,166 @@
+/*
+ * include/adi_hip.h -- C ABI of libadi_hip.so, the MI355X (gfx950) ADI heat-equation hot path.
+ *
+ * The reference (Matemusi/ADI_thermal_fields) has no FFI: its boundary is a Python module
+ * namespace (`import adi3d_numba_coeff as adi` / `import adi3d_gpu_coeff as adi`,
+ * waam_from_stl_v7_mm.py:321-335).  This header is what a binding for that namespace calls;
+ * each entry point cites the reference function it replaces.  adi_thermal_fields_amd/ binds
+ * it with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, every call returns int (ADI_OK == 0) and never throws.
+ *   - adi_last_error() returns a thread-local, human-readable message for the last failure.
+ *   - Fields are C-order (n0, n1, n2) fp64 arrays; masks are 1 byte per cell (0 / non-zero)
+ *     (adi3d_numba_coeff.py:14-19, :29-36).  Axis 2 is contiguous.
+ *   - "d_" pointers are DEVICE pointers owned by the caller (hipMalloc / torch); "h_" pointers are
+ *     host pointers borrowed for the duration of the call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Stateless entry points
+ *     only enqueue work; they never synchronise.
+ *   - Face order everywhere: 0 'x-', 1 'x+', 2 'y-', 3 'y+', 4 'z-', 5 'z+' (axis = face / 2).
+ */
+#ifndef ADI_HIP_H
+#define ADI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADI_OK              0
+#define ADI_ERR_ARG         1   /* bad argument (the Python host maps it to ValueError / AssertionError) */
+#define ADI_ERR_HIP         2   /* a HIP runtime call failed */
+#define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
+#define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
+
+#define ADI_ABI_VERSION 1
+
+/* per-face BC data mode for adi_build_coeffs */
+#define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
+#define ADI_FACE_SCALAR 1
+#define ADI_FACE_FIELD  2   /* per-voxel fp64 array */
+
+/* z-end boundary kinds of the cylindrical path (adi3d_cyl_phi_v3.py:60-68, :271-296) */
+#define ADI_ZBC_NEUMANN0  0
+#define ADI_ZBC_DIRICHLET 1
+#define ADI_ZBC_ROBIN     2
+
+/* sweep kernel variants (which pack arrays a sweep reads; selects the byte count of the roofline) */
+#define ADI_SWEEP_GENERAL   0   /* in, mask, coeff, dir_mask, dir_val, qflux -> out : 42 B/cell */
+#define ADI_SWEEP_NO_DIR    1   /* no Dirichlet cells: in, mask, coeff, qflux -> out : 33 B/cell */
+#define ADI_SWEEP_NO_Q      2   /* no Neumann flux:    in, mask, coeff, dir_mask, dir_val -> out : 34 B/cell */
+#define ADI_SWEEP_LEAN      3   /* neither:            in, mask, coeff -> out : 25 B/cell */
+
+int         adi_abi_version(void);
+const char *adi_last_error(void);
+int         adi_device_count(int *count);
+/* name: caller buffer of >= 256 bytes; cu_count / hbm_bytes / lds_per_cu may be NULL */
+int         adi_device_info(int device, char *name, int *cu_count, size_t *hbm_bytes, size_t *lds_per_cu);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stateless device entry points (caller-owned device memory).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* exposed_mask(mask, face): adi3d_numba_coeff.py:38-55 / adi3d_gpu_coeff.py:31-48 */
+int adi_exposed_mask(const uint8_t *d_mask, int nx, int ny, int nz, int face, uint8_t *d_exposed, void *stream);
+
+/*
+ * precompute_coeff_packs_unified: adi3d_numba_coeff.py:57-118 / adi3d_gpu_coeff.py:50-110.
+ * One pass over the grid writes the three Robin coefficient fields and the three Neumann flux fields:
+ *   coeff[axis] += h_f * dx^2 / (rho cp dx^3) on cells exposed on face f ('-' face first, then '+'),
+ *   qflux[axis] += q_f * dx^2 / (rho cp dx^3) on exposed cells.
+ * h_mode/q_mode[6]: ADI_FACE_*; h_scalar/q_scalar[6]; h_field/q_field[6]: device pointers or NULL.
+ * d_coeff[3], d_qflux[3]: device output fields (fully overwritten).
+ */
+int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, double dx, double rho, double cp,
+                     const int *h_mode, const double *h_scalar, const double *const *d_h_field,
+                     const int *q_mode, const double *q_scalar, const double *const *d_q_field,
+                     double *const *d_coeff, double *const *d_qflux, void *stream);
+
+/* lap1D_x/y/z + R0 = Tn + dt*kappa*(1-theta)*(Lx+Ly+Lz): adi3d_numba_coeff.py:240-288, :298 */
+int adi_explicit_rhs(const double *d_T, const uint8_t *d_mask, int nx, int ny, int nz, double dx,
+                     double dt, double kappa, double theta, double *d_R0, void *stream);
+
+/*
+ * sweep_axis0/1/2: adi3d_numba_coeff.py:133-237 (full-length identity-row form of
+ * adi3d_gpu_coeff.py:154-191).  One independent tridiagonal system per grid line along `axis`.
+ * variant: ADI_SWEEP_*; arrays a variant does not read may be NULL.
+ * d_out must not alias d_in.  d_work/work_bytes: scratch for lines longer than the in-register
+ * limit (adi_sweep_workspace_bytes); may be NULL/0 otherwise.
+ */
+int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_mask, const double *d_coeff,
+              const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux,
+              int nx, int ny, int nz, double theta, double gam, double dt, double Tinf,
+              double *d_out, void *d_work, size_t work_bytes, void *stream);
+int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, size_t *bytes);
+
+/*
+ * adi_step_numba_coeff / adi_step_gpu_coeff: adi3d_numba_coeff.py:290-302, adi3d_gpu_coeff.py:213-230.
+ * d_T_in is not modified; d_T_out receives the new field; d_tmp_a / d_tmp_b are two scratch fields.
+ * d_coeff[3], d_qflux[3]: per-axis pack arrays; dir data shared by the three packs (:116-118).
+ */
+int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b,
+             const uint8_t *d_mask, const double *const *d_coeff, const uint8_t *d_dir_mask,
+             const double *d_dir_val, const double *const *d_qflux, int variant,
+             int nx, int ny, int nz, double dx, double rho, double cp, double k,
+             double dt, double theta, double Tinf, void *d_work, size_t work_bytes, void *stream);
+
+/* T[sel != 0] = value   (layer birth: waam_from_stl_v7_mm.py:487-495 `T[newborn] = Ts`) */
+int adi_masked_fill(double *d_T, const uint8_t *d_sel, size_t n, double value, void *stream);
+/* dst = a | b  (birth bookkeeping: mask_act |= newborn) */
+int adi_mask_or(uint8_t *d_dst, const uint8_t *d_a, const uint8_t *d_b, size_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Cylindrical (r, phi, z) backward-Euler step: adi3d_cyl_phi_v3.py:332-350 (scheme="be").
+ * Field layout C-order (nr, nphi, nz).  d_S may be NULL (no source).  d_tmp_a/d_tmp_b: scratch fields.
+ * d_active (optional, may be NULL): adi_step_masked of quick_spiral_deposition_gif_v5.py:31-70 --
+ * void cells are clamped to T_void before and after the step, inactive axis-row cells to T_inner.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct adi_cyl_plan adi_cyl_plan;
+/* GridCyl + Material + Params(dt) + RobinR + ZBC (adi3d_cyl_phi_v3.py:33-68) frozen into device tables:
+ * the r coefficients of build_coeff_r (:155-202), the per-radius phi factors of phi_solve_spectral
+ * (:302-329) and the z closures of build_coeff_z (:255-298).  Created on the current device.
+ * ADI_ERR_ARG ("unknown zbc.kind_bot/top") mirrors the reference's ValueError (:283, :296). */
+int adi_cyl_plan_create(int nr, int nphi, int nz, double dr, double dphi, double dz,
+                        double rho, double cp, double k, double dt,
+                        double robin_h, double robin_Tinf,
+                        int kind_bot, int kind_top, double h_bot, double h_top,
+                        double Tinf_bot, double Tinf_top, double T_bot, double T_top,
+                        adi_cyl_plan **out);
+int adi_cyl_plan_destroy(adi_cyl_plan *plan);
+/* adi_step (BE): T_in is not modified; the four field buffers must be distinct. */
+int adi_cyl_step(const adi_cyl_plan *plan, const double *d_T_in, double *d_T_out,
+                 double *d_tmp_a, double *d_tmp_b, const double *d_S,
+                 const uint8_t *d_active, double T_void, double T_inner, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Context API: the library owns the device memory; callers hand over HOST arrays.
+ * One context per GPU and thread; no hidden global state.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct adi_ctx adi_ctx;
+
+/* Grid3D(nx,ny,nz,dx,mask): adi3d_numba_coeff.py:14-19 (mask copied) */
+int adi_ctx_create(int nx, int ny, int nz, double dx, int device, adi_ctx **out);
+int adi_ctx_destroy(adi_ctx *ctx);
+/* grid.mask = ... (drivers rebind the mask between steps: single_track_on_plate.py:159-160) */
+int adi_ctx_set_mask(adi_ctx *ctx, const uint8_t *h_mask);
+/* precompute_coeff_packs_unified with host-side BC data; h_dir_mask/h_dir_val may be NULL */
+int adi_ctx_build_coeffs(adi_ctx *ctx, double rho, double cp,
+                         const int *h_mode, const double *h_scalar, const double *const *h_h_field,
+                         const int *q_mode, const double *q_scalar, const double *const *h_q_field,
+                         const uint8_t *h_dir_mask, const double *h_dir_val);
+int adi_ctx_upload_T(adi_ctx *ctx, const double *h_T);
+int adi_ctx_download_T(adi_ctx *ctx, double *h_T);
+/* read the device-built pack arrays back (axis 0..2); any pointer may be NULL */
+int adi_ctx_download_pack(adi_ctx *ctx, int axis, double *h_coeff, double *h_qflux);
+/* nsteps calls of adi_step with the same packs and dt (drivers' inner loop,
+ * quick_compare_dirichlet_robin.py:169-178); T stays resident on the device */
+int adi_ctx_step(adi_ctx *ctx, double rho, double cp, double k, double dt, double theta, double Tinf, int nsteps);
+/* wall time in milliseconds of the last adi_ctx_step, measured with HIP events on the context's stream */
+int adi_ctx_last_step_ms(adi_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADI_HIP_H */
