@@ -32,7 +32,7 @@ from ._lib import lib, check, ptr_array, FACES
 
 __all__ = ['Grid3D', 'Material', 'Params', 'AxisCoeffPack', 'exposed_mask', 'precompute_coeff_packs_unified',
            'adi_step_hip_coeff', 'adi_step_numba_coeff', 'adi_step_gpu_coeff', 'DeviceField', 'to_device',
-           'adi_explicit_rhs', 'adi_sweep_axis']
+           'adi_explicit_rhs', 'adi_sweep_axis', 'StagedStepper']
 
 
 def _device():
@@ -411,3 +411,45 @@ def adi_step_hip_coeff(Tn, grid, mat, params, packs, Tinf=0.0):
 # the reference's backend-specific names, so its drivers run unchanged on this module
 adi_step_numba_coeff = adi_step_hip_coeff
 adi_step_gpu_coeff = adi_step_hip_coeff
+
+
+class StagedStepper:
+    """The step of adi_step_hip_coeff with its arguments resolved once, for tight loops over a
+    device-resident field (drivers call the step `nsub` times with the same packs and dt,
+    quick_compare_dirichlet_robin.py:169-178).  `events`: optional list of 5 torch.cuda.Event recorded on
+    the launch stream before/between/after the four stage kernels (per-stage HIP-event timing)."""
+
+    stage_names = ['explicit', 'sweep_axis0', 'sweep_axis1', 'sweep_axis2_contig']
+
+    def __init__(self, grid, mat, params, packs, Tinf=0.0):
+        self.grid, self.mat, self.params, self.packs, self.Tinf = grid, mat, params, packs, float(Tinf)
+        self.stage_bytes_per_cell = [_lib.EXPLICIT_BYTES_PER_CELL] + \
+            [_lib.SWEEP_BYTES_PER_CELL[p.variant] for p in packs]
+
+    def sweep_into(self, axis, t_in, t_out, variant=None):
+        if variant == _lib.SWEEP_GENERAL:
+            _ensure_general(self.packs[axis])
+        _sweep_into(axis, t_in, t_out, self.grid, self.mat, self.params, self.packs[axis], self.Tinf, variant)
+
+    def step(self, T, events=None):
+        g, prm = self.grid, self.params
+        t = T.t
+        (ta, tb), _, _ = g.scratch(2)
+        kappa, _ = _gam(g, self.mat, prm)
+        out = torch.empty_like(t)
+        if events is not None:
+            events[0].record()
+        check(lib.adi_explicit_rhs(_p(t), _p(g.d_mask), g.nx, g.ny, g.nz, g.dx, prm.dt, kappa, prm.theta,
+                                   _p(ta), _stream()))
+        if events is not None:
+            events[1].record()
+        self.sweep_into(0, ta, tb)
+        if events is not None:
+            events[2].record()
+        self.sweep_into(1, tb, ta)
+        if events is not None:
+            events[3].record()
+        self.sweep_into(2, ta, out)
+        if events is not None:
+            events[4].record()
+        return DeviceField(out)

@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: ADI steps/s and HBM GB/s, 512^3 fp64 Cartesian Robin, 1..8 MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 512] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full ADI time step (explicit stage + three implicit sweeps) of the hot path over a
+synthetic field that is already resident in HBM.  Workload (BASELINE.json configs[2] / SURVEY.md 8(d)
+config 3): n^3 cells per GPU (n = 512), all-solid mask, dx = 5e-4, steel, Robin h = 500 on all six faces,
+Tinf = 20, theta = 0.5, cfl = 200, T0 ~ U(20, 1000) seeded per rank.  For N > 1 the grid is (N*n, n, n)
+cut into slabs along memory axis 0 (weak scaling): halo planes for the explicit stage and the reduced
+interface system of the sharded-axis sweep travel over RCCL.
+
+Prints ONE JSON line on rank 0.  `value` = 512^3-cell-equivalent ADI steps per second summed over all
+ranks (= plain steps/s at N = 1, n = 512).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--n', type=int, default=512, help='cells per axis per GPU')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--cpu-n', type=int, default=192, help='edge of the bounded CPU-baseline sample')
+    return ap.parse_args()
+
+
+def cpu_baseline(n, seed=0):
+    """The oracle (oracle/adi_oracle.c, a port of the reference's Numba path) timed on this host's cores on a
+    bounded sample of the same workload.  Returns (single-thread dict, all-cores dict)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle import adi_oracle as orc
+    shape = (n, n, n)
+    grid = orc.Grid3D(n, n, n, 5e-4, np.ones(shape, bool))
+    mat = orc.Material(7800.0, 490.0, 54.0)
+    alpha = mat.k / (mat.rho * mat.cp)
+    prm = orc.Params(200.0 * grid.dx ** 2 / alpha, 0.5)
+    packs = orc.precompute_coeff_packs_unified(grid, mat, robin_h=500.0)
+    T0 = np.random.default_rng(seed).uniform(20.0, 1000.0, shape)
+    out = []
+    for omp, steps in ((False, 2), (True, 6)):
+        orc.adi_run(T0, grid, mat, prm, packs, Tinf=20.0, nsteps=1, omp=omp)   # warm (page faults, OpenMP pool)
+        t0 = time.perf_counter()
+        orc.adi_run(T0, grid, mat, prm, packs, Tinf=20.0, nsteps=steps, omp=omp)
+        dt = time.perf_counter() - t0
+        cells_per_s = steps * n ** 3 / dt
+        out.append(dict(value=cells_per_s / 512 ** 3, unit='steps/s (512^3-cell equivalent)',
+                        cores=(os.cpu_count() if omp else 1), kind='port',
+                        sample='%d^3 cells x %d steps of the same Robin workload, %.1f s, oracle/adi_oracle%s.c'
+                               % (n, steps, dt, '_omp' if omp else ''),
+                        cell_updates_per_s=cells_per_s))
+    return out
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.gpus > 1 and world == 1:
+        print('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % a.gpus,
+              file=sys.stderr)
+        sys.exit(2)
+    assert world == a.gpus, 'WORLD_SIZE (%d) != --gpus (%d)' % (world, a.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import adi_thermal_fields_amd.adi3d_hip_coeff as adi
+    from adi_thermal_fields_amd import _lib
+
+    n = a.n
+    mat = adi.Material(7800.0, 490.0, 54.0)
+    alpha = mat.k / (mat.rho * mat.cp)
+    dx = 5e-4
+    prm = adi.Params(200.0 * dx * dx / alpha, 0.5)
+    Tinf = 20.0
+    gen = torch.Generator(device=dev); gen.manual_seed(1 + rank)
+    T0 = torch.rand((n, n, n), dtype=torch.float64, device=dev, generator=gen) * 980.0 + 20.0
+
+    stage_names = ['explicit', 'sweep_axis0', 'sweep_axis1', 'sweep_axis2_contig']
+    if world == 1:
+        grid = adi.Grid3D(n, n, n, dx, np.ones((n, n, n), bool))
+        packs = adi.precompute_coeff_packs_unified(grid, mat, robin_h=500.0)
+        T = adi.DeviceField(T0)
+        stepper = adi.StagedStepper(grid, mat, prm, packs, Tinf)
+        variant = packs[0].variant
+    else:
+        from adi_thermal_fields_amd import dist_slab
+        stepper = dist_slab.SlabStepper.from_local(T0, np.ones((n, n, n), bool), dx, mat, prm, Tinf,
+                                                   robin_h=500.0)
+        T = adi.DeviceField(T0)
+        variant = stepper.variant
+        stage_names = stepper.stage_names
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        T = stepper.step(T)
+    nst = len(stage_names)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(a.steps)]
+    sync()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        T = stepper.step(T, events=ev[s])     # HIP events on the launch stream between the stage kernels
+    sync()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = elapsed.item()
+    assert bool(torch.isfinite(T.t).all().item())
+
+    stage_ms = np.array([[ev[s][i].elapsed_time(ev[s][i + 1]) for i in range(nst)] for s in range(a.steps)])
+    mean_ms = stage_ms.mean(axis=0)
+    N = n ** 3
+    bytes_per_cell = dict(zip(stage_names, stepper.stage_bytes_per_cell))
+    kernels = {}
+    for i, nm in enumerate(stage_names):
+        gbs = bytes_per_cell[nm] * N / (mean_ms[i] * 1e-3) / 1e9
+        kernels[nm] = dict(ms=round(float(mean_ms[i]), 4), bytes_per_cell=bytes_per_cell[nm],
+                           achieved_gbs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # general-pack (42 B/cell) contiguous-axis sweep: the kernel the 60 % target is written against; measured
+    # outside the timed region of the step loop with the same event method
+    xs = None
+    if world == 1:
+        Tin = T
+        ms = []
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        out = torch.empty_like(Tin.t)
+        for it in range(13):
+            e0.record()
+            stepper.sweep_into(2, Tin.t, out, variant=_lib.SWEEP_GENERAL)
+            e1.record(); e1.synchronize()
+            if it >= 3:
+                ms.append(e0.elapsed_time(e1))
+        m = float(np.mean(ms))
+        xs = dict(kernel='k_sweep_contig<8,vec,dir,q> (general pack)', ms=round(m, 4), bytes_per_cell=42,
+                  achieved_gbs=round(42 * N / (m * 1e-3) / 1e9, 1),
+                  frac=round(42 * N / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+
+    dom = max(kernels, key=lambda k: kernels[k]['ms'])
+    traffic = None
+    tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get(dom)
+        except Exception:
+            traffic = None
+    ms_per_step = elapsed / a.steps * 1e3
+    value = world * N / 512 ** 3 * a.steps / elapsed
+    line = dict(
+        metric='adi_steps_per_sec_512cubed_fp64', value=round(value, 3),
+        unit='steps/s (512^3-cell equivalent, all GPUs)', n_gpus=world, steps=a.steps, warmup=a.warmup,
+        ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling='weak', vs_baseline=None,
+        dtype='f64', data='synthetic',
+        config=dict(workload='%dx%dx%d fp64 Cartesian, Robin h=500 all faces, theta=0.5, cfl=200, all-solid mask'
+                             % (world * n, n, n),
+                    cells_per_gpu=N, decomposition=('none' if world == 1 else 'slabs along memory axis 0'),
+                    sweep_variant={0: 'general', 1: 'no_dir', 2: 'no_q', 3: 'lean'}[variant]),
+        cell_updates_per_s=round(world * N * a.steps / elapsed, 1),
+        step_achieved_gbs=round(sum(bytes_per_cell.values()) * N / (ms_per_step * 1e-3) / 1e9, 1),
+        roofline=dict(bound='hbm', kernel=dom, achieved=kernels[dom]['achieved_gbs'], peak=HBM_PEAK_GBS,
+                      unit='GB/s', frac=kernels[dom]['frac'], traffic=traffic),
+        kernels=kernels,
+    )
+    if xs is not None:
+        line['xsweep_general_pack'] = xs
+    if world == 1 and not a.no_cpu:
+        st, mt = cpu_baseline(a.cpu_n)
+        line['cpu_baseline'] = st
+        line['cpu_baseline_all_cores'] = mt
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
