@@ -41,6 +41,7 @@ SIGNATURES = {
     'adi_build_coeffs': (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_double, c_double,
                                  c_int_p, c_double_p, c_void_pp, c_int_p, c_double_p, c_void_pp,
                                  c_void_pp, c_void_pp, c_void_p]),
+    'adi_build_nbr_flags': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'adi_explicit_rhs': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double,
                                  c_void_p, c_void_p]),
     'adi_sweep': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

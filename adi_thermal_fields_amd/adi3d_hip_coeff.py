@@ -144,6 +144,7 @@ class Grid3D:
         self.dx = float(dx)
         self._mask = None
         self._d_mask = None
+        self._d_flags = None
         self._scratch = None
         self.mask_version = 0
         self.mask = np.asarray(mask).astype(np.bool_, copy=True, order='C')
@@ -168,12 +169,19 @@ class Grid3D:
     def sync_mask(self):
         """(Re)upload the host mask; called on assignment and by precompute_coeff_packs_unified."""
         self._d_mask = _upload(self._mask, torch.uint8)
+        self._d_flags = torch.empty_like(self._d_mask)
+        check(lib.adi_build_nbr_flags(_p(self._d_mask), self.nx, self.ny, self.nz, _p(self._d_flags), _stream()))
         self.mask_version += 1
         return self._d_mask
 
     @property
     def d_mask(self):
         return self._d_mask
+
+    @property
+    def d_flags(self):
+        """neighbour-flags digest of the mask (adi_build_nbr_flags), what the step kernels read"""
+        return self._d_flags
 
     def scratch(self, n):
         """n cached scratch fields + the long-line workspace (None when not needed)."""
@@ -355,7 +363,7 @@ def adi_explicit_rhs(Tn, grid, mat, params):
     t, kind = _as_state(Tn, grid)
     kappa, _ = _gam(grid, mat, params)
     out = torch.empty_like(t)
-    check(lib.adi_explicit_rhs(_p(t), _p(grid.d_mask), grid.nx, grid.ny, grid.nz, grid.dx, params.dt, kappa,
+    check(lib.adi_explicit_rhs(_p(t), _p(grid.d_flags), grid.nx, grid.ny, grid.nz, grid.dx, params.dt, kappa,
                                params.theta, _p(out), _stream()))
     return _wrap(out, kind)
 
@@ -364,7 +372,7 @@ def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None):
     _, gam = _gam(grid, mat, params)
     _, work, wb = grid.scratch(2)
     v = pack.variant if variant is None else variant
-    check(lib.adi_sweep(axis, v, _p(t_in), _p(grid.d_mask), _p(pack.d_coeff), _p(pack.d_dir_mask),
+    check(lib.adi_sweep(axis, v, _p(t_in), _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
                         _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz,
                         params.theta, gam, params.dt, float(Tinf), _p(t_out), _p(work), wb, _stream()))
 
@@ -400,7 +408,7 @@ def adi_step_hip_coeff(Tn, grid, mat, params, packs, Tinf=0.0):
     (ta, tb), _, _ = grid.scratch(2)
     kappa, _ = _gam(grid, mat, params)
     out = torch.empty_like(t)
-    check(lib.adi_explicit_rhs(_p(t), _p(grid.d_mask), grid.nx, grid.ny, grid.nz, grid.dx, params.dt, kappa,
+    check(lib.adi_explicit_rhs(_p(t), _p(grid.d_flags), grid.nx, grid.ny, grid.nz, grid.dx, params.dt, kappa,
                                params.theta, _p(ta), _stream()))
     _sweep_into(0, ta, tb, grid, mat, params, packx, Tinf)
     _sweep_into(1, tb, ta, grid, mat, params, packy, Tinf)
@@ -439,7 +447,7 @@ class StagedStepper:
         out = torch.empty_like(t)
         if events is not None:
             events[0].record()
-        check(lib.adi_explicit_rhs(_p(t), _p(g.d_mask), g.nx, g.ny, g.nz, g.dx, prm.dt, kappa, prm.theta,
+        check(lib.adi_explicit_rhs(_p(t), _p(g.d_flags), g.nx, g.ny, g.nz, g.dx, prm.dt, kappa, prm.theta,
                                    _p(ta), _stream()))
         if events is not None:
             events[1].record()

@@ -13,6 +13,8 @@
 // Data layout: C-order (n0, n1, n2) fp64 fields and 1-byte masks, exactly the reference's
 // (adi3d_numba_coeff.py:18, :31-36); axis 2 is contiguous.  All kernels are HBM-bandwidth bound
 // (< 1 flop/byte); no MFMA.
+#include <stdlib.h>
+
 #include "adi_common.hpp"
 #include "adi_core.hpp"
 
@@ -75,42 +77,42 @@ __device__ __forceinline__ void load_rows_contig(const double *__restrict__ p, l
     }
 }
 
-// M mask bytes -> M bits (bit r set when byte r is non-zero)
+// M flag/mask bytes of a lane's chunk, one byte per row in `b[r]`
 template <int M, bool VEC>
-__device__ __forceinline__ unsigned load_bits_contig(const uint8_t *__restrict__ p, long base, int r0, int n,
-                                                     bool active)
+__device__ __forceinline__ void load_bytes_contig(const uint8_t *__restrict__ p, long base, int r0, int n,
+                                                  bool active, unsigned (&b)[M])
 {
-    unsigned bits = 0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) b[r] = 0;
     if (VEC) {
         if (active && r0 < n) {
             if (M == 2) {
                 const unsigned w = *reinterpret_cast<const uint16_t *>(p + base);
-                bits = ((w & 0xffu) ? 1u : 0u) | ((w >> 8) ? 2u : 0u);
+                b[0] = w & 0xffu;
+                b[1] = w >> 8;
             } else if (M == 4) {
                 const unsigned w = *reinterpret_cast<const uint32_t *>(p + base);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bits |= (((w >> (8 * r)) & 0xffu) ? 1u : 0u) << r;
+                for (int r = 0; r < 4; ++r) b[r] = (w >> (8 * r)) & 0xffu;
             } else {
 #pragma unroll
                 for (int h = 0; h < M / 8; ++h) {
                     const uint64_t w = *reinterpret_cast<const uint64_t *>(p + base + 8 * h);
 #pragma unroll
-                    for (int r = 0; r < 8; ++r)
-                        bits |= ((unsigned)(((w >> (8 * r)) & 0xffull) ? 1u : 0u)) << (8 * h + r);
+                    for (int r = 0; r < 8; ++r) b[8 * h + r] = (unsigned)((w >> (8 * r)) & 0xffull);
                 }
             }
         }
     } else {
 #pragma unroll
         for (int r = 0; r < M; ++r)
-            if (active && r0 + r < n && p[base + r]) bits |= 1u << r;
+            if (active && r0 + r < n) b[r] = p[base + r];
     }
-    return bits;
 }
 
 template <int M, bool VEC, bool HAS_DIR, bool HAS_Q>
 __global__ __launch_bounds__(256) void k_sweep_contig(
-    const double *__restrict__ in, const uint8_t *__restrict__ mask, const double *__restrict__ coeff,
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ out, long nlines, int n, int Lp, SweepScal s)
 {
@@ -127,24 +129,15 @@ __global__ __launch_bounds__(256) void k_sweep_contig(
     load_rows_contig<M, VEC>(coeff, base, r0, n, active, vco);
     if (HAS_DIR) load_rows_contig<M, VEC>(dval, base, r0, n, active, vdv);
     if (HAS_Q) load_rows_contig<M, VEC>(qf, base, r0, n, active, vq);
-    const unsigned mb = load_bits_contig<M, VEC>(mask, base, r0, n, active);
-    unsigned db = 0;
-    if (HAS_DIR) db = load_bits_contig<M, VEC>(dmask, base, r0, n, active);
-
-    // mask bit of the row just before / after this lane's chunk (other lanes of the same line)
-    const unsigned up = __shfl_up(mb, 1, Lp), dn = __shfl_down(mb, 1, Lp);
-    const bool mPrev = (li > 0) && ((up >> (M - 1)) & 1u);
-    const bool mNext = (li < Lp - 1) && (dn & 1u);
+    unsigned fb[M], db[M];
+    load_bytes_contig<M, VEC>(flags, base, r0, n, active, fb);
+    if (HAS_DIR) load_bytes_contig<M, VEC>(dmask, base, r0, n, active, db);
 
     double a[M], b[M], c[M], d[M];
 #pragma unroll
-    for (int r = 0; r < M; ++r) {
-        const bool m = (mb >> r) & 1u;
-        const bool mL = (r == 0) ? mPrev : ((mb >> (r - 1)) & 1u);
-        const bool mR = (r == M - 1) ? mNext : ((mb >> (r + 1)) & 1u);
-        assemble_row<HAS_DIR, HAS_Q>(m, mL, mR, HAS_DIR && ((db >> r) & 1u), vin[r], vco[r],
-                                     HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r], c[r], d[r]);
-    }
+    for (int r = 0; r < M; ++r)   // flags: bit0 cell in mask, bit5 / bit6 the z- / z+ neighbour is in the mask
+        assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> 5) & 1u, (fb[r] >> 6) & 1u, HAS_DIR && db[r] != 0, vin[r],
+                                     vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r], c[r], d[r]);
 
     double ip[M - 1];
     Cond k;
@@ -181,10 +174,10 @@ __global__ __launch_bounds__(256) void k_sweep_contig(
 // ------------------------------------------------------------------------------------------------
 template <int M, bool HAS_DIR, bool HAS_Q>
 __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
-    const double *__restrict__ in, const uint8_t *__restrict__ mask, const double *__restrict__ coeff,
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ out, int n, long stride, int n_inner, long outer_stride, int Lp, int LINES,
-    int tiles_inner, long ntiles, SweepScal s)
+    int tiles_inner, long ntiles, int lbit, SweepScal s)
 {
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x;
@@ -200,16 +193,12 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
     double a[M], b[M], c[M], d[M];
     {
         double vin[M], vco[M], vdv[M], vq[M];
-        bool mk[M + 2];
-#pragma unroll
-        for (int r = 0; r < M + 2; ++r) {
-            const int row = r0 - 1 + r;
-            mk[r] = active && row >= 0 && row < n && mask[base + (long)row * stride] != 0;
-        }
+        unsigned fb[M];
 #pragma unroll
         for (int r = 0; r < M; ++r) {
             const bool ok = active && (r0 + r) < n;
             const long p = base + (long)(r0 + r) * stride;
+            fb[r] = ok ? flags[p] : 0u;
             vin[r] = ok ? in[p] : 0.0;
             vco[r] = ok ? coeff[p] : 0.0;
             if (HAS_DIR) vdv[r] = ok ? dval[p] : 0.0;
@@ -219,8 +208,8 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
         for (int r = 0; r < M; ++r) {
             bool dir = false;
             if (HAS_DIR) dir = active && (r0 + r) < n && dmask[base + (long)(r0 + r) * stride] != 0;
-            assemble_row<HAS_DIR, HAS_Q>(mk[r + 1], mk[r], mk[r + 2], dir, vin[r], vco[r], HAS_DIR ? vdv[r] : 0.0,
-                                         HAS_Q ? vq[r] : 0.0, s, a[r], b[r], c[r], d[r]);
+            assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> lbit) & 1u, (fb[r] >> (lbit + 1)) & 1u, dir, vin[r],
+                                         vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r], c[r], d[r]);
         }
     }
 
@@ -273,30 +262,27 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
 // ------------------------------------------------------------------------------------------------
 template <bool HAS_DIR, bool HAS_Q>
 __global__ __launch_bounds__(256) void k_sweep_generic(
-    const double *__restrict__ in, const uint8_t *__restrict__ mask, const double *__restrict__ coeff,
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ out, int n, long stride, long n_inner, long inner_stride, long n_outer,
-    long outer_stride, double *__restrict__ wc, double *__restrict__ wd, SweepScal s)
+    long outer_stride, int lbit, double *__restrict__ wc, double *__restrict__ wd, SweepScal s)
 {
     const long lid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (lid >= n_inner * n_outer) return;
     const long o = lid / n_inner, kc = lid - o * n_inner;
     const long base = o * outer_stride + kc * inner_stride;
-    bool mPrev = false, mCur = mask[base] != 0;
     double cp = 0.0, dp = 0.0;
     for (int r = 0; r < n; ++r) {
         const long p = base + (long)r * stride;
-        const bool mNext = (r + 1 < n) && mask[p + stride] != 0;
+        const unsigned f = flags[p];
         double a, b, c, d;
-        assemble_row<HAS_DIR, HAS_Q>(mCur, mPrev, mNext, HAS_DIR && dmask[p] != 0, in[p], coeff[p],
-                                     HAS_DIR ? dval[p] : 0.0, HAS_Q ? qf[p] : 0.0, s, a, b, c, d);
+        assemble_row<HAS_DIR, HAS_Q>(f & 1u, (f >> lbit) & 1u, (f >> (lbit + 1)) & 1u, HAS_DIR && dmask[p] != 0, in[p],
+                                     coeff[p], HAS_DIR ? dval[p] : 0.0, HAS_Q ? qf[p] : 0.0, s, a, b, c, d);
         const double inv = 1.0 / (b - a * cp);
         cp = c * inv;
         dp = (d - a * dp) * inv;
         wc[p] = cp;
         wd[p] = dp;
-        mPrev = mCur;
-        mCur = mNext;
     }
     double x = 0.0;
     for (int r = n - 1; r >= 0; --r) {
@@ -308,45 +294,141 @@ __global__ __launch_bounds__(256) void k_sweep_generic(
 
 // ------------------------------------------------------------------------------------------------
 // K1: explicit stage.  Expression order is the reference's and FMA contraction is off, so R0 is
-// bit-identical to the NumPy evaluation.  Tiles are ordered [j-slab][i][j][k-tile] and handed to XCDs
-// in contiguous chunks: an XCD streams one j-slab plane by plane, so the i+-1 neighbour planes of a
-// slab (3 x 256 KiB at 512^2) stay in that XCD's 4 MiB L2 and HBM sees each T line once.
+// bit-identical to the NumPy evaluation.  Reads the neighbour-flags byte (bit0 cell in mask, bits 1..6:
+// the x-,x+,y-,y+,z-,z+ neighbour is in the mask) instead of seven mask bytes.
+//
+// k_explicit_v2: a thread owns two adjacent k-cells (16-byte accesses) and marches over JR consecutive
+// j-rows with a three-row register window, so per cell pair it issues three dwordx4 loads (row j+1 and
+// the i-1 / i+1 planes); the k-neighbours come from the adjacent lanes.  Tiles are ordered
+// [j-slab][i][j-chunk][k-tile] and handed to XCDs in contiguous chunks: an XCD streams one j-slab plane by
+// plane, so the i+-1 planes of a slab (3 x 256 KiB at 512^2) stay in that XCD's 4 MiB L2 and HBM sees each
+// T line once.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_explicit(const double *__restrict__ T, const uint8_t *__restrict__ mask,
-                                                  double *__restrict__ R0, int nx, int ny, int nz,
-                                                  double invdx2, double f, int jslab, int ktiles, long ntiles)
+__device__ __forceinline__ double lap_axis(bool lo, bool hi, double tlo, double thi, double t, double invdx2)
 {
 #pragma clang fp contract(off)
-    // tile = 4 j-rows x 64 k
+    double sacc = 0.0, cnt = 0.0;   // s = 0; if lower in mask: s += T_lo; c += 1; ... (adi3d_numba_coeff.py:246-253)
+    if (lo) { sacc += tlo; cnt += 1.0; }
+    if (hi) { sacc += thi; cnt += 1.0; }
+    return (sacc - cnt * t) * invdx2;
+}
+
+constexpr int kExplicitJR = 8;
+
+__global__ __launch_bounds__(256) void k_explicit_v2(const double *__restrict__ T, const uint8_t *__restrict__ flags,
+                                                     double *__restrict__ R0, int nx, int ny, int nz,
+                                                     double invdx2, double f, int jslab, int ktiles, long ntiles)
+{
+#pragma clang fp contract(off)
     const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
-    const int jt_per_slab = (jslab + 3) / 4;
-    const long per_plane = (long)jt_per_slab * ktiles;
+    const int jc_per_slab = (jslab + kExplicitJR - 1) / kExplicitJR;
+    const long per_plane = (long)jc_per_slab * ktiles;
     const long per_slab = per_plane * nx;
     const int slab = (int)(tile / per_slab);
     long rem = tile - (long)slab * per_slab;
     const int i = (int)(rem / per_plane);
     rem -= (long)i * per_plane;
-    const int jt = (int)(rem / ktiles), kt = (int)(rem - (long)jt * ktiles);
-    const int jl = jt * 4 + (threadIdx.x >> 6);
-    const int j = slab * jslab + jl;
-    const int k = kt * 64 + (threadIdx.x & 63);
-    if (jl >= jslab || j >= ny || k >= nz) return;
+    const int jc = (int)(rem / ktiles), kt = (int)(rem - (long)jc * ktiles);
+    const int jbeg = slab * jslab + jc * kExplicitJR;
+    int jend = jbeg + kExplicitJR;
+    if (jend > (slab + 1) * jslab) jend = (slab + 1) * jslab;
+    if (jend > ny) jend = ny;
+    const int k0 = kt * 512 + 2 * (int)threadIdx.x;
+    const bool kin = k0 < nz;            // nz is even: both cells of the pair are inside
+    const int lane = threadIdx.x & 63;
     const long sx = (long)ny * nz, sy = nz;
-    const long p = (long)i * sx + (long)j * sy + k;
-    const double t = T[p];
-    double L[3] = {0.0, 0.0, 0.0};
-    if (mask[p]) {
-        const int pos[3] = {i, j, k}, nn[3] = {nx, ny, nz};
-        const long st[3] = {sx, sy, 1};
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            double sacc = 0.0, cnt = 0.0;
-            if (pos[ax] - 1 >= 0 && mask[p - st[ax]]) { sacc += T[p - st[ax]]; cnt += 1.0; }
-            if (pos[ax] + 1 < nn[ax] && mask[p + st[ax]]) { sacc += T[p + st[ax]]; cnt += 1.0; }
-            L[ax] = (sacc - cnt * t) * invdx2;
-        }
+    if (jbeg >= jend) return;
+    long p = (long)i * sx + (long)jbeg * sy + k0;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    double2 tm = zero2, tc = zero2, tp = zero2;
+    if (kin) {
+        tc = *reinterpret_cast<const double2 *>(T + p);
+        if (jbeg > 0) tm = *reinterpret_cast<const double2 *>(T + p - sy);
     }
-    R0[p] = t + f * ((L[0] + L[1]) + L[2]);
+    for (int j = jbeg; j < jend; ++j, p += sy) {
+        unsigned fl = 0;
+        double2 ti0 = zero2, ti1 = zero2;
+        if (kin) {
+            fl = *reinterpret_cast<const uint16_t *>(flags + p);
+            if (j + 1 < ny) tp = *reinterpret_cast<const double2 *>(T + p + sy);
+            if (i > 0) ti0 = *reinterpret_cast<const double2 *>(T + p - sx);
+            if (i + 1 < nx) ti1 = *reinterpret_cast<const double2 *>(T + p + sx);
+        }
+        // k-neighbours of the pair: adjacent lanes, wave edges from memory
+        double kl = __shfl_up(tc.y, 1), kr = __shfl_down(tc.x, 1);
+        if (lane == 0) kl = (kin && k0 > 0) ? T[p - 1] : 0.0;
+        if (lane == 63) kr = (kin && k0 + 2 < nz) ? T[p + 2] : 0.0;
+        const unsigned f0 = fl & 0xffu, f1 = fl >> 8;
+        double r0v, r1v;
+        {
+            double L0 = 0.0, L1 = 0.0, L2 = 0.0;
+            if (f0 & 1u) {
+                L0 = lap_axis(f0 & 2u, f0 & 4u, ti0.x, ti1.x, tc.x, invdx2);
+                L1 = lap_axis(f0 & 8u, f0 & 16u, tm.x, tp.x, tc.x, invdx2);
+                L2 = lap_axis(f0 & 32u, f0 & 64u, kl, tc.y, tc.x, invdx2);
+            }
+            r0v = tc.x + f * ((L0 + L1) + L2);
+        }
+        {
+            double L0 = 0.0, L1 = 0.0, L2 = 0.0;
+            if (f1 & 1u) {
+                L0 = lap_axis(f1 & 2u, f1 & 4u, ti0.y, ti1.y, tc.y, invdx2);
+                L1 = lap_axis(f1 & 8u, f1 & 16u, tm.y, tp.y, tc.y, invdx2);
+                L2 = lap_axis(f1 & 32u, f1 & 64u, tc.x, kr, tc.y, invdx2);
+            }
+            r1v = tc.y + f * ((L0 + L1) + L2);
+        }
+        if (kin) *reinterpret_cast<double2 *>(R0 + p) = make_double2(r0v, r1v);
+        tm = tc;
+        tc = tp;
+    }
+}
+
+// generic form (odd nz or unaligned views): one cell per thread
+__global__ __launch_bounds__(256) void k_explicit(const double *__restrict__ T, const uint8_t *__restrict__ flags,
+                                                  double *__restrict__ R0, int nx, int ny, int nz,
+                                                  double invdx2, double f)
+{
+#pragma clang fp contract(off)
+    const long N = (long)nx * ny * nz;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const long sx = (long)ny * nz, sy = nz;
+    const double t = T[p];
+    const unsigned fl = flags[p];
+    double L0 = 0.0, L1 = 0.0, L2 = 0.0;
+    if (fl & 1u) {
+        L0 = lap_axis(fl & 2u, fl & 4u, (fl & 2u) ? T[p - sx] : 0.0, (fl & 4u) ? T[p + sx] : 0.0, t, invdx2);
+        L1 = lap_axis(fl & 8u, fl & 16u, (fl & 8u) ? T[p - sy] : 0.0, (fl & 16u) ? T[p + sy] : 0.0, t, invdx2);
+        L2 = lap_axis(fl & 32u, fl & 64u, (fl & 32u) ? T[p - 1] : 0.0, (fl & 64u) ? T[p + 1] : 0.0, t, invdx2);
+    }
+    R0[p] = t + f * ((L0 + L1) + L2);
+}
+
+// neighbour flags: bit0 = cell in mask, bit(1 + 2*axis) / bit(2 + 2*axis) = the minus / plus neighbour along
+// `axis` exists and is in the mask.  Derived from the mask whenever it changes (the mask "folds into the
+// coefficient build on device"); halo planes of a slab decomposition are simply part of the mask array.
+__global__ __launch_bounds__(256) void k_build_flags(const uint8_t *__restrict__ mask, int nx, int ny, int nz,
+                                                     uint8_t *__restrict__ flags)
+{
+    const long N = (long)nx * ny * nz;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const int k = (int)(p % nz);
+    const long ij = p / nz;
+    const int j = (int)(ij % ny), i = (int)(ij / ny);
+    const long sx = (long)ny * nz, sy = nz;
+    unsigned f = 0;
+    if (mask[p]) {
+        f = 1u;
+        if (i > 0 && mask[p - sx]) f |= 2u;
+        if (i + 1 < nx && mask[p + sx]) f |= 4u;
+        if (j > 0 && mask[p - sy]) f |= 8u;
+        if (j + 1 < ny && mask[p + sy]) f |= 16u;
+        if (k > 0 && mask[p - 1]) f |= 32u;
+        if (k + 1 < nz && mask[p + 1]) f |= 64u;
+    }
+    flags[p] = (uint8_t)f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -433,6 +515,19 @@ __global__ __launch_bounds__(256) void k_mask_or(uint8_t *__restrict__ dst, cons
 // ------------------------------------------------------------------------------------------------
 // host-side launch logic
 // ------------------------------------------------------------------------------------------------
+// lines per strided tile (8 B * lines contiguous per row).  16 = whole 128-byte lines; ADI_STRIDED_LINES
+// overrides for tuning runs.
+static int strided_lines_pref()
+{
+    static int v = 0;
+    if (v == 0) {
+        const char *e = getenv("ADI_STRIDED_LINES");
+        v = e ? atoi(e) : 16;
+        if (v != 8 && v != 16 && v != 32) v = 16;
+    }
+    return v;
+}
+
 static int contig_rows_per_lane(int n) { return n <= 128 ? 2 : (n <= 256 ? 4 : (n <= 512 ? 8 : 16)); }
 static int strided_rows_per_thread(int n) { return n <= 16 ? 2 : (n <= 32 ? 4 : (n <= 512 ? 8 : 16)); }
 
@@ -459,17 +554,17 @@ static void launch_contig(const double *in, const uint8_t *mask, const double *c
 template <int M, bool HAS_DIR, bool HAS_Q>
 static void launch_strided(const double *in, const uint8_t *mask, const double *coeff, const uint8_t *dmask,
                            const double *dval, const double *qf, double *out, int n, long stride, int n_inner,
-                           long n_outer, long outer_stride, SweepScal s, hipStream_t st)
+                           long n_outer, long outer_stride, int lbit, SweepScal s, hipStream_t st)
 {
     const int Lp = next_pow2((n + M - 1) / M);
-    int lines = (M <= 8) ? 16 : 8;  // M = 16 keeps 512-thread workgroups (register budget)
+    int lines = (M <= 8) ? strided_lines_pref() : 8;  // M = 16 keeps 512-thread workgroups (register budget)
     while (lines * Lp < 256) lines <<= 1;
     const int tiles_inner = (n_inner + lines - 1) / lines;
     const long ntiles = (long)tiles_inner * n_outer;
     const size_t lds = (size_t)8 * lines * (Lp + 1) * sizeof(double);
     hipLaunchKernelGGL((k_sweep_strided<M, HAS_DIR, HAS_Q>), dim3((unsigned)ntiles), dim3(lines * Lp), lds, st, in,
                        mask, coeff, dmask, dval, qf, out, n, stride, n_inner, outer_stride, Lp, lines, tiles_inner,
-                       ntiles, s);
+                       ntiles, lbit, s);
 }
 
 template <bool HAS_DIR, bool HAS_Q>
@@ -492,7 +587,7 @@ static int sweep_dispatch(int axis, const double *in, const uint8_t *mask, const
         const long nl = n_inner * n_outer;
         hipLaunchKernelGGL((k_sweep_generic<HAS_DIR, HAS_Q>), dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, in,
                            mask, coeff, dmask, dval, qf, out, n, stride, n_inner, inner_stride, n_outer, outer_stride,
-                           wc, wd, s);
+                           1 + 2 * axis, wc, wd, s);
         return ADI_OK;
     }
     if (axis == 2) {
@@ -511,10 +606,10 @@ static int sweep_dispatch(int axis, const double *in, const uint8_t *mask, const
         if (n_inner_l > 0x7fffffffL) return set_err(ADI_ERR_UNSUPPORTED, "adi_sweep: plane too large");
         const int n_inner = (int)n_inner_l;
         switch (strided_rows_per_thread(n)) {
-            case 2: launch_strided<2, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, n, stride, n_inner, n_outer, outer_stride, s, st); break;
-            case 4: launch_strided<4, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, n, stride, n_inner, n_outer, outer_stride, s, st); break;
-            case 8: launch_strided<8, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, n, stride, n_inner, n_outer, outer_stride, s, st); break;
-            default: launch_strided<16, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, n, stride, n_inner, n_outer, outer_stride, s, st); break;
+            case 2: launch_strided<2, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, n, stride, n_inner, n_outer, outer_stride, 1 + 2 * axis, s, st); break;
+            case 4: launch_strided<4, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, n, stride, n_inner, n_outer, outer_stride, 1 + 2 * axis, s, st); break;
+            case 8: launch_strided<8, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, n, stride, n_inner, n_outer, outer_stride, 1 + 2 * axis, s, st); break;
+            default: launch_strided<16, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, n, stride, n_inner, n_outer, outer_stride, 1 + 2 * axis, s, st); break;
         }
     }
     return ADI_OK;
@@ -562,19 +657,36 @@ int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, double dx, d
     return ADI_OK;
 }
 
-int adi_explicit_rhs(const double *d_T, const uint8_t *d_mask, int nx, int ny, int nz, double dx, double dt,
+int adi_build_nbr_flags(const uint8_t *d_mask, int nx, int ny, int nz, uint8_t *d_flags, void *stream)
+{
+    ADI_REQUIRE(d_mask && d_flags && nx > 0 && ny > 0 && nz > 0, "adi_build_nbr_flags: bad argument");
+    const long N = (long)nx * ny * nz;
+    hipLaunchKernelGGL(k_build_flags, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), d_mask, nx,
+                       ny, nz, d_flags);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, double dx, double dt,
                      double kappa, double theta, double *d_R0, void *stream)
 {
-    ADI_REQUIRE(d_T && d_mask && d_R0 && nx > 0 && ny > 0 && nz > 0, "adi_explicit_rhs: bad argument");
+    ADI_REQUIRE(d_T && d_flags && d_R0 && nx > 0 && ny > 0 && nz > 0, "adi_explicit_rhs: bad argument");
     ADI_REQUIRE(d_T != d_R0, "adi_explicit_rhs: output aliases input");
     const double invdx2 = 1.0 / (dx * dx);
     const double f = dt * kappa * (1.0 - theta);
-    const int jslab = (ny + 7) / 8;
-    const int nslab = (ny + jslab - 1) / jslab;
-    const int ktiles = (nz + 63) / 64;
-    const long ntiles = (long)nslab * nx * ((jslab + 3) / 4) * ktiles;
-    hipLaunchKernelGGL(k_explicit, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_mask, d_R0, nx, ny,
-                       nz, invdx2, f, jslab, ktiles, ntiles);
+    const bool fast = (nz % 2 == 0) && ((((uintptr_t)d_T | (uintptr_t)d_R0) & 15) == 0) && (((uintptr_t)d_flags & 1) == 0);
+    if (fast) {
+        const int jslab = (ny + 7) / 8;
+        const int nslab = (ny + jslab - 1) / jslab;
+        const int ktiles = (nz + 511) / 512;
+        const long ntiles = (long)nslab * nx * ((jslab + kExplicitJR - 1) / kExplicitJR) * ktiles;
+        hipLaunchKernelGGL(k_explicit_v2, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
+                           nx, ny, nz, invdx2, f, jslab, ktiles, ntiles);
+    } else {
+        const long N = (long)nx * ny * nz;
+        hipLaunchKernelGGL(k_explicit, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), d_T,
+                           d_flags, d_R0, nx, ny, nz, invdx2, f);
+    }
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }
@@ -587,14 +699,14 @@ int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, size_t *bytes)
     return ADI_OK;
 }
 
-int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_mask, const double *d_coeff,
+int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
               const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
               double theta, double gam, double dt, double Tinf, double *d_out, void *d_work, size_t work_bytes,
               void *stream)
 {
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep: bad axis %d", axis);
     ADI_REQUIRE(variant >= 0 && variant <= 3, "adi_sweep: bad variant %d", variant);
-    ADI_REQUIRE(d_in && d_mask && d_coeff && d_out && nx > 0 && ny > 0 && nz > 0, "adi_sweep: bad argument");
+    ADI_REQUIRE(d_in && d_flags && d_coeff && d_out && nx > 0 && ny > 0 && nz > 0, "adi_sweep: bad argument");
     ADI_REQUIRE(d_in != d_out, "adi_sweep: output aliases input");
     const bool has_dir = (variant == ADI_SWEEP_GENERAL || variant == ADI_SWEEP_NO_Q);
     const bool has_q = (variant == ADI_SWEEP_GENERAL || variant == ADI_SWEEP_NO_DIR);
@@ -606,16 +718,16 @@ int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_mask, 
     s.Tinf = Tinf;
     hipStream_t st = as_stream(stream);
     int rc;
-    if (has_dir && has_q) rc = sweep_dispatch<true, true>(axis, d_in, d_mask, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, s, d_out, d_work, work_bytes, st);
-    else if (has_q) rc = sweep_dispatch<false, true>(axis, d_in, d_mask, d_coeff, nullptr, nullptr, d_qflux, nx, ny, nz, s, d_out, d_work, work_bytes, st);
-    else if (has_dir) rc = sweep_dispatch<true, false>(axis, d_in, d_mask, d_coeff, d_dir_mask, d_dir_val, nullptr, nx, ny, nz, s, d_out, d_work, work_bytes, st);
-    else rc = sweep_dispatch<false, false>(axis, d_in, d_mask, d_coeff, nullptr, nullptr, nullptr, nx, ny, nz, s, d_out, d_work, work_bytes, st);
+    if (has_dir && has_q) rc = sweep_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, s, d_out, d_work, work_bytes, st);
+    else if (has_q) rc = sweep_dispatch<false, true>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, d_qflux, nx, ny, nz, s, d_out, d_work, work_bytes, st);
+    else if (has_dir) rc = sweep_dispatch<true, false>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, nullptr, nx, ny, nz, s, d_out, d_work, work_bytes, st);
+    else rc = sweep_dispatch<false, false>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, nullptr, nx, ny, nz, s, d_out, d_work, work_bytes, st);
     if (rc != ADI_OK) return rc;
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }
 
-int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b, const uint8_t *d_mask,
+int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b, const uint8_t *d_flags,
              const double *const *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
              const double *const *d_qflux, int variant, int nx, int ny, int nz, double dx, double rho, double cp,
              double k, double dt, double theta, double Tinf, void *d_work, size_t work_bytes, void *stream)
@@ -627,13 +739,13 @@ int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_t
     const double kappa = k / (rho * cp);
     const double gam = kappa * dt / (dx * dx);
     const double *q0 = d_qflux ? d_qflux[0] : nullptr, *q1 = d_qflux ? d_qflux[1] : nullptr, *q2 = d_qflux ? d_qflux[2] : nullptr;
-    int rc = adi_explicit_rhs(d_T_in, d_mask, nx, ny, nz, dx, dt, kappa, theta, d_tmp_a, stream);
+    int rc = adi_explicit_rhs(d_T_in, d_flags, nx, ny, nz, dx, dt, kappa, theta, d_tmp_a, stream);
     if (rc) return rc;
-    rc = adi_sweep(0, variant, d_tmp_a, d_mask, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, theta, gam, dt, Tinf, d_tmp_b, d_work, work_bytes, stream);
+    rc = adi_sweep(0, variant, d_tmp_a, d_flags, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, theta, gam, dt, Tinf, d_tmp_b, d_work, work_bytes, stream);
     if (rc) return rc;
-    rc = adi_sweep(1, variant, d_tmp_b, d_mask, d_coeff[1], d_dir_mask, d_dir_val, q1, nx, ny, nz, theta, gam, dt, Tinf, d_tmp_a, d_work, work_bytes, stream);
+    rc = adi_sweep(1, variant, d_tmp_b, d_flags, d_coeff[1], d_dir_mask, d_dir_val, q1, nx, ny, nz, theta, gam, dt, Tinf, d_tmp_a, d_work, work_bytes, stream);
     if (rc) return rc;
-    return adi_sweep(2, variant, d_tmp_a, d_mask, d_coeff[2], d_dir_mask, d_dir_val, q2, nx, ny, nz, theta, gam, dt, Tinf, d_T_out, d_work, work_bytes, stream);
+    return adi_sweep(2, variant, d_tmp_a, d_flags, d_coeff[2], d_dir_mask, d_dir_val, q2, nx, ny, nz, theta, gam, dt, Tinf, d_T_out, d_work, work_bytes, stream);
 }
 
 int adi_masked_fill(double *d_T, const uint8_t *d_sel, size_t n, double value, void *stream)

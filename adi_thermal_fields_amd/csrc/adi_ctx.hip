@@ -31,7 +31,7 @@ struct adi_ctx {
     int nx, ny, nz, device;
     double dx;
     size_t N;
-    uint8_t *mask, *dir_mask;
+    uint8_t *mask, *flags, *dir_mask;
     double *T[2];        // ping-pong state
     double *tmp[2];      // stage scratch
     double *coeff[3], *qflux[3], *dir_val;
@@ -49,7 +49,7 @@ static void ctx_free(adi_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->mask, c->dir_mask, c->T[0], c->T[1], c->tmp[0], c->tmp[1], c->coeff[0], c->coeff[1],
+    void *ptrs[] = {c->mask, c->flags, c->dir_mask, c->T[0], c->T[1], c->tmp[0], c->tmp[1], c->coeff[0], c->coeff[1],
                     c->coeff[2], c->qflux[0], c->qflux[1], c->qflux[2], c->dir_val, c->work};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -105,6 +105,7 @@ int adi_ctx_create(int nx, int ny, int nz, double dx, int device, adi_ctx **out)
         }                                                                              \
     } while (0)
     CTX_ALLOC(c->mask, c->N);
+    CTX_ALLOC(c->flags, c->N);
     CTX_ALLOC(c->dir_mask, c->N);
     CTX_ALLOC(c->dir_val, fb);
     for (int i = 0; i < 2; ++i) { CTX_ALLOC(c->T[i], fb); CTX_ALLOC(c->tmp[i], fb); }
@@ -138,6 +139,8 @@ int adi_ctx_set_mask(adi_ctx *c, const uint8_t *h_mask)
     ADI_REQUIRE(c && h_mask, "adi_ctx_set_mask: null argument");
     ADI_HIP_TRY(hipSetDevice(c->device));
     ADI_HIP_TRY(hipMemcpyAsync(c->mask, h_mask, c->N, hipMemcpyHostToDevice, c->stream));
+    int rc = adi_build_nbr_flags(c->mask, c->nx, c->ny, c->nz, c->flags, c->stream);
+    if (rc != ADI_OK) return rc;
     ADI_HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_mask = true;
     c->have_packs = false;  // packs depend on the mask: rebuild before the next step
@@ -242,7 +245,7 @@ int adi_ctx_step(adi_ctx *c, double rho, double cp, double k, double dt, double 
     ADI_HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (int s = 0; s < nsteps; ++s) {
         const int nxt = c->cur ^ 1;
-        int rc = adi_step(c->T[c->cur], c->T[nxt], c->tmp[0], c->tmp[1], c->mask, c->coeff, c->dir_mask, c->dir_val,
+        int rc = adi_step(c->T[c->cur], c->T[nxt], c->tmp[0], c->tmp[1], c->flags, c->coeff, c->dir_mask, c->dir_val,
                           c->qflux, c->variant, c->nx, c->ny, c->nz, c->dx, rho, cp, k, dt, theta, Tinf, c->work,
                           c->work_bytes, c->stream);
         if (rc != ADI_OK) return rc;

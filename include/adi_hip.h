@@ -47,7 +47,7 @@ extern "C" {
 #define ADI_ZBC_ROBIN     2
 
 /* sweep kernel variants (which pack arrays a sweep reads; selects the byte count of the roofline) */
-#define ADI_SWEEP_GENERAL   0   /* in, mask, coeff, dir_mask, dir_val, qflux -> out : 42 B/cell */
+#define ADI_SWEEP_GENERAL   0   /* in, flags, coeff, dir_mask, dir_val, qflux -> out : 42 B/cell */
 #define ADI_SWEEP_NO_DIR    1   /* no Dirichlet cells: in, mask, coeff, qflux -> out : 33 B/cell */
 #define ADI_SWEEP_NO_Q      2   /* no Neumann flux:    in, mask, coeff, dir_mask, dir_val -> out : 34 B/cell */
 #define ADI_SWEEP_LEAN      3   /* neither:            in, mask, coeff -> out : 25 B/cell */
@@ -78,8 +78,17 @@ int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, double dx, d
                      const int *q_mode, const double *q_scalar, const double *const *d_q_field,
                      double *const *d_coeff, double *const *d_qflux, void *stream);
 
+/*
+ * Neighbour flags, the device-side digest of the mask every step kernel reads instead of the raw mask:
+ *   bit0 = cell in mask; bit(1+2a) / bit(2+2a) = the minus / plus neighbour along axis a exists and is in
+ *   the mask (the `mask[i-1,j,k]` / `mask[i+1,j,k]` tests of adi3d_numba_coeff.py:150-153, :246-251).
+ * Rebuild whenever the mask changes (same moment the packs are rebuilt, waam_from_stl_v7_mm.py:494-495, :534).
+ * For a slab of a larger grid, build the flags on the slab plus its two halo planes and pass the interior.
+ */
+int adi_build_nbr_flags(const uint8_t *d_mask, int nx, int ny, int nz, uint8_t *d_flags, void *stream);
+
 /* lap1D_x/y/z + R0 = Tn + dt*kappa*(1-theta)*(Lx+Ly+Lz): adi3d_numba_coeff.py:240-288, :298 */
-int adi_explicit_rhs(const double *d_T, const uint8_t *d_mask, int nx, int ny, int nz, double dx,
+int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, double dx,
                      double dt, double kappa, double theta, double *d_R0, void *stream);
 
 /*
@@ -89,7 +98,7 @@ int adi_explicit_rhs(const double *d_T, const uint8_t *d_mask, int nx, int ny, i
  * d_out must not alias d_in.  d_work/work_bytes: scratch for lines longer than the in-register
  * limit (adi_sweep_workspace_bytes); may be NULL/0 otherwise.
  */
-int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_mask, const double *d_coeff,
+int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
               const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux,
               int nx, int ny, int nz, double theta, double gam, double dt, double Tinf,
               double *d_out, void *d_work, size_t work_bytes, void *stream);
@@ -101,7 +110,7 @@ int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, size_t *bytes);
  * d_coeff[3], d_qflux[3]: per-axis pack arrays; dir data shared by the three packs (:116-118).
  */
 int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b,
-             const uint8_t *d_mask, const double *const *d_coeff, const uint8_t *d_dir_mask,
+             const uint8_t *d_flags, const double *const *d_coeff, const uint8_t *d_dir_mask,
              const double *d_dir_val, const double *const *d_qflux, int variant,
              int nx, int ny, int nz, double dx, double rho, double cp, double k,
              double dt, double theta, double Tinf, void *d_work, size_t work_bytes, void *stream);
