@@ -522,8 +522,8 @@ static int strided_lines_pref()
     static int v = 0;
     if (v == 0) {
         const char *e = getenv("ADI_STRIDED_LINES");
-        v = e ? atoi(e) : 16;
-        if (v != 8 && v != 16 && v != 32) v = 16;
+        v = e ? atoi(e) : 8;
+        if (v != 8 && v != 16) v = 8;
     }
     return v;
 }

@@ -24,10 +24,12 @@ def timeit(fn, n=10, warm=3):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     shape = (n, n, n)
-    N = n ** 3
+    if len(sys.argv) > 3:
+        shape = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
+    N = shape[0] * shape[1] * shape[2]
     dev = torch.device('cuda')
     mask = np.ones(shape, bool)
-    grid = adi.Grid3D(n, n, n, 5e-4, mask)
+    grid = adi.Grid3D(shape[0], shape[1], shape[2], 5e-4, mask)
     mat = adi.Material(7800.0, 490.0, 54.0)
     alpha = mat.k / (mat.rho * mat.cp)
     prm = adi.Params(200.0 * grid.dx ** 2 / alpha, 0.5)

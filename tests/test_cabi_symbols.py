@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, 'include', 'adi_hip.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(adi_[a-z0-9_]+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(adi_[A-Za-z0-9_]+)\s*\(', src)))
 
 
 def test_header_symbols_exported_and_bound():
