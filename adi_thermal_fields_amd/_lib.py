@@ -27,6 +27,7 @@ if not os.path.exists(LIB_PATH):
 lib = ctypes.CDLL(LIB_PATH)
 
 c_int, c_double, c_void_p, c_size_t = ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+c_long = ctypes.c_long
 c_int_p = ctypes.POINTER(c_int)
 c_double_p = ctypes.POINTER(c_double)
 c_void_pp = ctypes.POINTER(c_void_p)
@@ -37,23 +38,28 @@ SIGNATURES = {
     'adi_last_error': (ctypes.c_char_p, []),
     'adi_device_count': (c_int, [c_int_p]),
     'adi_device_info': (c_int, [c_int, ctypes.c_char_p, c_int_p, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
-    'adi_exposed_mask': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    'adi_build_coeffs': (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_double, c_double,
+    'adi_recommended_plane_stride': (ctypes.c_long, [c_int, c_int]),
+    'adi_exposed_mask': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p, c_void_p]),
+    'adi_build_coeffs': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_double, c_double, c_double,
                                  c_int_p, c_double_p, c_void_pp, c_int_p, c_double_p, c_void_pp,
                                  c_void_pp, c_void_pp, c_void_p]),
-    'adi_build_nbr_flags': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    'adi_explicit_rhs': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double,
-                                 c_void_p, c_void_p]),
+    'adi_build_nbr_flags': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p]),
+    'adi_explicit_rhs': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_double, c_double, c_double,
+                                 c_double, c_void_p, c_void_p]),
     'adi_sweep': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                          c_int, c_int, c_int, c_double, c_double, c_double, c_double,
-                          c_void_p, c_void_p, c_size_t, c_void_p]),
-    'adi_sweep_workspace_bytes': (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
+                          c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double,
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'adi_sweep_workspace_bytes': (c_int, [c_int, c_int, c_int, c_int, c_long, ctypes.POINTER(c_size_t)]),
+    'adi_sweep_condense': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double,
+                                   c_void_p, c_void_p]),
+    'adi_interface_solve': (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
     'adi_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_pp, c_void_p, c_void_p,
-                         c_void_pp, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double,
+                         c_void_pp, c_int, c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double,
                          c_double, c_double, c_double, c_void_p, c_size_t, c_void_p]),
     'adi_masked_fill': (c_int, [c_void_p, c_void_p, c_size_t, c_double, c_void_p]),
     'adi_mask_or': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    'adi_cyl_plan_create': (c_int, [c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_double,
+    'adi_cyl_plan_create': (c_int, [c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double, c_double, c_double,
                                     c_double, c_double, c_double, c_int, c_int, c_double, c_double, c_double,
                                     c_double, c_double, c_double, c_void_pp]),
     'adi_cyl_plan_destroy': (c_int, [c_void_p]),

@@ -17,9 +17,13 @@ Residency: a NumPy `Tn` is uploaded, stepped and downloaded (exact reference sem
 out, input untouched).  Pass a `DeviceField` (see `to_device`) to keep the state in HBM across
 steps -- the step then returns a new DeviceField, like the CuPy backend returns CuPy arrays.
 
+Device layout: fields live in HBM with a padded plane stride (`Layout.sx`, chosen by
+adi_recommended_plane_stride) so that the rows of an axis-0 line do not alias on the HBM channel
+interleave; the C-order (nx, ny, nz) shape of the reference is what every host-visible view has.
+
 Mask semantics: drivers rebind `grid.mask` and then rebuild the packs
 (single_track_on_plate.py:159-163, waam_from_stl_v7_mm.py:494-495, :534).  The device copy of the
-mask is refreshed on every `grid.mask = ...` assignment AND on every
+mask (and its neighbour-flags digest) is refreshed on every `grid.mask = ...` assignment AND on every
 precompute_coeff_packs_unified(grid, ...) call, which is the documented synchronisation point.
 """
 import ctypes
@@ -32,7 +36,7 @@ from ._lib import lib, check, ptr_array, FACES
 
 __all__ = ['Grid3D', 'Material', 'Params', 'AxisCoeffPack', 'exposed_mask', 'precompute_coeff_packs_unified',
            'adi_step_hip_coeff', 'adi_step_numba_coeff', 'adi_step_gpu_coeff', 'DeviceField', 'to_device',
-           'adi_explicit_rhs', 'adi_sweep_axis', 'StagedStepper']
+           'adi_explicit_rhs', 'adi_sweep_axis', 'StagedStepper', 'Layout']
 
 
 def _device():
@@ -50,21 +54,55 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def _upload(a, dtype):
-    """host array -> contiguous device tensor (bool masks travel as uint8)."""
-    if isinstance(a, DeviceField):
-        a = a.t
-    if isinstance(a, torch.Tensor):
-        t = a.to(device=_device())
-        if dtype == torch.uint8 and t.dtype == torch.bool:
-            t = t.view(torch.uint8) if t.is_contiguous() else t.contiguous().view(torch.uint8)
-        return t.to(dtype).contiguous()
-    arr = np.asarray(a)
-    if dtype == torch.uint8:
-        arr = np.ascontiguousarray(arr.astype(np.bool_, copy=False)).view(np.uint8)
-    else:
-        arr = np.ascontiguousarray(arr, dtype=np.float64)
-    return torch.from_numpy(arr).to(_device())
+class Layout:
+    """Device layout of a (nx, ny, nz) grid: element (i, j, k) at i*sx + j*nz + k."""
+
+    def __init__(self, nx, ny, nz, sx=None):
+        self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
+        self.sx = int(lib.adi_recommended_plane_stride(self.ny, self.nz)) if sx is None else int(sx)
+        assert self.sx >= self.ny * self.nz
+
+    @property
+    def shape(self):
+        return (self.nx, self.ny, self.nz)
+
+    @property
+    def strides(self):
+        return (self.sx, self.nz, 1)
+
+    @property
+    def numel_padded(self):
+        return self.nx * self.sx
+
+    def empty(self, dtype=torch.float64, zero=False):
+        buf = (torch.zeros if zero else torch.empty)(self.numel_padded, dtype=dtype, device=_device())
+        return buf.as_strided(self.shape, self.strides)
+
+    def is_native(self, t):
+        return (isinstance(t, torch.Tensor) and t.is_cuda and tuple(t.shape) == self.shape
+                and tuple(t.stride()) == self.strides and t.storage_offset() == 0)
+
+    def to_layout(self, a, dtype):
+        """host array / tensor / DeviceField -> tensor in this layout (a copy unless already native)."""
+        if isinstance(a, DeviceField):
+            a = a.t
+        if isinstance(a, torch.Tensor):
+            if self.is_native(a) and a.dtype == dtype:
+                return a
+            src = a.to(device=_device())
+            if dtype == torch.uint8 and src.dtype == torch.bool:
+                src = src.to(torch.uint8)
+        else:
+            arr = np.asarray(a)
+            if dtype == torch.uint8:
+                arr = np.ascontiguousarray(arr.astype(np.bool_, copy=False)).view(np.uint8)
+            else:
+                arr = np.ascontiguousarray(arr, dtype=np.float64)   # fp32 fields are up-cast (waam --precision float32)
+            src = torch.from_numpy(arr)
+        assert tuple(src.shape) == self.shape, (tuple(src.shape), self.shape)
+        out = self.empty(dtype, zero=(dtype == torch.uint8 and self.sx != self.ny * self.nz))
+        out.copy_(src.to(dtype) if src.dtype != dtype else src)
+        return out
 
 
 class DeviceField:
@@ -72,7 +110,7 @@ class DeviceField:
     drivers: indexing returns NumPy data, item assignment writes through, `np.asarray(f)` downloads."""
 
     def __init__(self, tensor):
-        assert tensor.dtype == torch.float64 and tensor.is_cuda and tensor.is_contiguous()
+        assert tensor.dtype == torch.float64 and tensor.is_cuda and tensor.dim() == 3
         self.t = tensor
 
     shape = property(lambda self: tuple(self.t.shape))
@@ -81,14 +119,19 @@ class DeviceField:
     dtype = np.dtype(np.float64)
 
     def get(self):
-        return self.t.cpu().numpy()
+        return self.t.cpu().contiguous().numpy()
 
     def __array__(self, dtype=None, copy=None):
         a = self.get()
         return a if dtype is None else a.astype(dtype, copy=False)
 
     def copy(self):
-        return DeviceField(self.t.clone())
+        if self.t.is_contiguous() or self.t.storage_offset() != 0:
+            return DeviceField(self.t.clone())
+        t = torch.empty(self.t.shape[0] * self.t.stride(0), dtype=self.t.dtype, device=self.t.device) \
+            .as_strided(self.t.shape, self.t.stride())
+        t.copy_(self.t)
+        return DeviceField(t)
 
     def astype(self, dtype, copy=True):
         return self.get().astype(dtype, copy=False)
@@ -106,15 +149,18 @@ class DeviceField:
         return r.item() if r.dim() == 0 else r.cpu().numpy()
 
     def __setitem__(self, idx, value):
-        if isinstance(idx, np.ndarray) and idx.dtype == np.bool_ and idx.shape == self.shape and np.isscalar(value):
-            sel = _upload(idx, torch.uint8)   # T[newborn] = Ts (waam_from_stl_v7_mm.py:491-493)
-            check(lib.adi_masked_fill(_p(self.t), _p(sel), self.t.numel(), float(value), _stream()))
-            return
+        # T[newborn] = Ts / T[idx] = Ts (waam_from_stl_v7_mm.py:489-493) and general slices
         if isinstance(value, np.ndarray):
             value = torch.from_numpy(np.ascontiguousarray(value, dtype=np.float64)).to(_device())
         elif isinstance(value, DeviceField):
             value = value.t
         self.t[self._idx(idx)] = value
+
+    def fill_where(self, d_sel_native, value):
+        """T[sel] = value with `sel` a uint8 tensor in the same device layout (HIP kernel, no host round trip)."""
+        assert tuple(d_sel_native.stride()) == tuple(self.t.stride())
+        n = self.t.shape[0] * self.t.stride(0)
+        check(lib.adi_masked_fill(_p(self.t), _p(d_sel_native), n, float(value), _stream()))
 
     def min(self):
         return self.t.min().item()
@@ -130,10 +176,11 @@ class DeviceField:
 
 
 def to_device(T):
-    """NumPy (nx, ny, nz) field -> DeviceField (a copy, like the constructors of the reference)."""
+    """NumPy (nx, ny, nz) field -> DeviceField in the library's device layout (a copy)."""
     if isinstance(T, DeviceField):
         return T.copy()
-    return DeviceField(_upload(T, torch.float64).clone() if isinstance(T, torch.Tensor) else _upload(T, torch.float64))
+    t = Layout(*tuple(T.shape)).to_layout(T, torch.float64)
+    return DeviceField(t.clone() if (isinstance(T, torch.Tensor) and t is T) else t)
 
 
 class Grid3D:
@@ -142,6 +189,7 @@ class Grid3D:
     def __init__(self, nx, ny, nz, dx, mask):
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         self.dx = float(dx)
+        self.layout = Layout(self.nx, self.ny, self.nz)
         self._mask = None
         self._d_mask = None
         self._d_flags = None
@@ -152,6 +200,10 @@ class Grid3D:
     @property
     def shape(self):
         return (self.nx, self.ny, self.nz)
+
+    @property
+    def sx(self):
+        return self.layout.sx
 
     @property
     def mask(self):
@@ -167,10 +219,12 @@ class Grid3D:
         self.sync_mask()
 
     def sync_mask(self):
-        """(Re)upload the host mask; called on assignment and by precompute_coeff_packs_unified."""
-        self._d_mask = _upload(self._mask, torch.uint8)
-        self._d_flags = torch.empty_like(self._d_mask)
-        check(lib.adi_build_nbr_flags(_p(self._d_mask), self.nx, self.ny, self.nz, _p(self._d_flags), _stream()))
+        """(Re)upload the host mask and rebuild its neighbour-flags digest; called on assignment and by
+        precompute_coeff_packs_unified."""
+        self._d_mask = self.layout.to_layout(self._mask, torch.uint8)
+        self._d_flags = self.layout.empty(torch.uint8, zero=True)
+        check(lib.adi_build_nbr_flags(_p(self._d_mask), self.nx, self.ny, self.nz, self.sx, _p(self._d_flags),
+                                      _stream()))
         self.mask_version += 1
         return self._d_mask
 
@@ -186,11 +240,11 @@ class Grid3D:
     def scratch(self, n):
         """n cached scratch fields + the long-line workspace (None when not needed)."""
         if self._scratch is None or len(self._scratch[0]) < n or self._scratch[0][0].device != _device():
-            fields = [torch.empty(self.shape, dtype=torch.float64, device=_device()) for _ in range(n)]
+            fields = [self.layout.empty() for _ in range(n)]
             wb = 0
             for ax in range(3):
                 b = ctypes.c_size_t(0)
-                check(lib.adi_sweep_workspace_bytes(ax, self.nx, self.ny, self.nz, ctypes.byref(b)))
+                check(lib.adi_sweep_workspace_bytes(ax, self.nx, self.ny, self.nz, self.sx, ctypes.byref(b)))
                 wb = max(wb, b.value)
             work = torch.empty(wb, dtype=torch.uint8, device=_device()) if wb else None
             self._scratch = (fields, work, wb)
@@ -208,22 +262,24 @@ class Params:  # adi3d_numba_coeff.py:25-27
 
 
 class AxisCoeffPack:
-    """adi3d_numba_coeff.py:29-36.  Arrays live in HBM (`d_*` tensors); the reference's attribute names
-    `.coeff / .dir_mask / .dir_val / .qflux` return host copies (drivers read `packs[2].qflux`,
-    quick_compare_neumann_robin.py:104)."""
+    """adi3d_numba_coeff.py:29-36.  Arrays live in HBM (`d_*` tensors, device layout); the reference's
+    attribute names `.coeff / .dir_mask / .dir_val / .qflux` return host copies (drivers read
+    `packs[2].qflux`, quick_compare_neumann_robin.py:104)."""
 
-    def __init__(self, coeff, dir_mask, dir_val, qflux=None, _has_dir=None, _has_q=None):
-        self.d_coeff = _upload(coeff, torch.float64)
-        self.d_dir_mask = None if dir_mask is None else _upload(dir_mask, torch.uint8)
-        self.d_dir_val = None if dir_val is None else _upload(dir_val, torch.float64)
-        self.d_qflux = None if qflux is None else _upload(qflux, torch.float64)
+    def __init__(self, coeff, dir_mask, dir_val, qflux=None, _has_dir=None, _has_q=None, _layout=None):
+        self.layout = _layout or Layout(*tuple(coeff.shape))
+        L = self.layout
+        self.d_coeff = L.to_layout(coeff, torch.float64)
+        self.d_dir_mask = None if dir_mask is None else L.to_layout(dir_mask, torch.uint8)
+        self.d_dir_val = None if dir_val is None else L.to_layout(dir_val, torch.float64)
+        self.d_qflux = None if qflux is None else L.to_layout(qflux, torch.float64)
         if _has_dir is None:
             _has_dir = self.d_dir_mask is not None and bool(self.d_dir_mask.any().item())
         if _has_q is None:
             _has_q = self.d_qflux is not None and bool((self.d_qflux != 0).any().item())
         self.has_dir, self.has_q = bool(_has_dir), bool(_has_q)
         if self.has_dir and self.d_dir_val is None:
-            self.d_dir_val = torch.zeros_like(self.d_coeff)
+            self.d_dir_val = L.empty(zero=True)
 
     @property
     def variant(self):
@@ -231,27 +287,15 @@ class AxisCoeffPack:
             return _lib.SWEEP_GENERAL if self.has_q else _lib.SWEEP_NO_Q
         return _lib.SWEEP_NO_DIR if self.has_q else _lib.SWEEP_LEAN
 
-    @property
-    def coeff(self):
-        return self.d_coeff.cpu().numpy()
+    def _host(self, t, dtype):
+        if t is None:
+            return np.zeros(self.layout.shape, dtype=dtype)
+        return t.cpu().contiguous().numpy().astype(dtype, copy=False)
 
-    @property
-    def qflux(self):
-        if self.d_qflux is None:
-            return np.zeros(tuple(self.d_coeff.shape), dtype=np.float64)
-        return self.d_qflux.cpu().numpy()
-
-    @property
-    def dir_mask(self):
-        if self.d_dir_mask is None:
-            return np.zeros(tuple(self.d_coeff.shape), dtype=np.bool_)
-        return self.d_dir_mask.cpu().numpy().astype(np.bool_)
-
-    @property
-    def dir_val(self):
-        if self.d_dir_val is None:
-            return np.zeros(tuple(self.d_coeff.shape), dtype=np.float64)
-        return self.d_dir_val.cpu().numpy()
+    coeff = property(lambda self: self._host(self.d_coeff, np.float64))
+    qflux = property(lambda self: self._host(self.d_qflux, np.float64))
+    dir_mask = property(lambda self: self._host(self.d_dir_mask, np.bool_))
+    dir_val = property(lambda self: self._host(self.d_dir_val, np.float64))
 
 
 def exposed_mask(mask, face):
@@ -259,22 +303,22 @@ def exposed_mask(mask, face):
     if face not in FACES:
         raise ValueError("bad face")
     host = not isinstance(mask, (torch.Tensor, DeviceField))
-    d = _upload(mask, torch.uint8)
-    assert d.dim() == 3
-    out = torch.empty_like(d)
-    nx, ny, nz = d.shape
-    check(lib.adi_exposed_mask(_p(d), nx, ny, nz, FACES.index(face), _p(out), _stream()))
+    shape = tuple(mask.shape)
+    assert len(shape) == 3
+    L = Layout(*shape, sx=shape[1] * shape[2])
+    d = L.to_layout(mask, torch.uint8)
+    out = L.empty(torch.uint8)
+    check(lib.adi_exposed_mask(_p(d), shape[0], shape[1], shape[2], 0, FACES.index(face), _p(out), _stream()))
     return out.cpu().numpy().astype(np.bool_) if host else out.to(torch.bool)
 
 
-def _face_spec(spec, shape, keep):
+def _face_spec(spec, L, keep):
     """scalar / array / None -> (mode, scalar, device tensor or None)"""
     if spec is None:
         return (_lib.FACE_NONE, 0.0, None)
     if np.isscalar(spec):
         return (_lib.FACE_SCALAR, float(spec), None)
-    t = _upload(spec, torch.float64)
-    assert tuple(t.shape) == shape
+    t = L.to_layout(spec, torch.float64)
     keep.append(t)
     return (_lib.FACE_FIELD, 0.0, t)
 
@@ -284,7 +328,7 @@ def precompute_coeff_packs_unified(grid, mat, dir_mask=None, dir_value=None, neu
     """adi3d_numba_coeff.py:57-118: one HIP pass builds the Robin coefficient and Neumann flux fields
     of the three axes on the device.  `robin_Tinf` is accepted and ignored, as in the reference (the
     ambient enters at step time)."""
-    shape = grid.shape
+    L = grid.layout
     d_mask = grid.sync_mask()
     keep = []
     h_specs, q_specs = [], []
@@ -292,25 +336,24 @@ def precompute_coeff_packs_unified(grid, mat, dir_mask=None, dir_value=None, neu
         if robin_h is None:
             h_specs.append((_lib.FACE_NONE, 0.0, None))
         elif isinstance(robin_h, dict):
-            h_specs.append(_face_spec(robin_h.get(f, 0.0), shape, keep))
+            h_specs.append(_face_spec(robin_h.get(f, 0.0), L, keep))
         else:
-            h_specs.append(_face_spec(robin_h, shape, keep))
-        q_specs.append(_face_spec(neumann.get(f) if neumann is not None else None, shape, keep))
+            h_specs.append(_face_spec(robin_h, L, keep))
+        q_specs.append(_face_spec(neumann.get(f) if neumann is not None else None, L, keep))
     if neumann is not None:
         for f in neumann:
             if f not in FACES:
                 raise ValueError("bad face")   # exposed_mask(grid.mask, f) raises in the reference (:106)
 
-    dev = _device()
-    coeff = [torch.empty(shape, dtype=torch.float64, device=dev) for _ in range(3)]
-    qflux = [torch.empty(shape, dtype=torch.float64, device=dev) for _ in range(3)]
+    coeff = [L.empty() for _ in range(3)]
+    qflux = [L.empty() for _ in range(3)]
     hm = (ctypes.c_int * 6)(*[s[0] for s in h_specs])
     hs = (ctypes.c_double * 6)(*[s[1] for s in h_specs])
     hf = ptr_array([s[2].data_ptr() if s[2] is not None else None for s in h_specs])
     qm = (ctypes.c_int * 6)(*[s[0] for s in q_specs])
     qs = (ctypes.c_double * 6)(*[s[1] for s in q_specs])
     qf = ptr_array([s[2].data_ptr() if s[2] is not None else None for s in q_specs])
-    check(lib.adi_build_coeffs(_p(d_mask), grid.nx, grid.ny, grid.nz, grid.dx, mat.rho, mat.cp,
+    check(lib.adi_build_coeffs(_p(d_mask), grid.nx, grid.ny, grid.nz, grid.sx, grid.dx, mat.rho, mat.cp,
                                hm, hs, hf, qm, qs, qf,
                                ptr_array([c.data_ptr() for c in coeff]), ptr_array([q.data_ptr() for q in qflux]),
                                _stream()))
@@ -318,16 +361,17 @@ def precompute_coeff_packs_unified(grid, mat, dir_mask=None, dir_value=None, neu
     d_dm = d_dv = None
     has_dir = False
     if dir_mask is not None:
-        d_dm = _upload(dir_mask, torch.uint8)
-        assert tuple(d_dm.shape) == shape
+        d_dm = L.to_layout(dir_mask, torch.uint8)
         has_dir = bool(d_dm.any().item())
         if dir_value is None:
-            d_dv = torch.zeros(shape, dtype=torch.float64, device=dev)          # :75-76
+            d_dv = L.empty(zero=True)                                   # :75-76
         elif np.isscalar(dir_value):
-            d_dv = torch.full(shape, float(dir_value), dtype=torch.float64, device=dev)  # :77-78
+            d_dv = L.empty()
+            d_dv.fill_(float(dir_value))                                # :77-78
         else:
-            d_dv = _upload(dir_value, torch.float64)
-    packs = tuple(AxisCoeffPack(coeff[a], d_dm, d_dv, qflux[a], _has_dir=has_dir, _has_q=has_q) for a in range(3))
+            d_dv = L.to_layout(dir_value, torch.float64)
+    packs = tuple(AxisCoeffPack(coeff[a], d_dm, d_dv, qflux[a], _has_dir=has_dir, _has_q=has_q, _layout=L)
+                  for a in range(3))
     for p in packs:
         p.mask_version = grid.mask_version
     return packs
@@ -339,15 +383,12 @@ def _gam(grid, mat, params):
 
 
 def _as_state(Tn, grid):
-    """-> (device tensor fp64 contiguous, kind) with kind in {'numpy', 'field', 'torch'}"""
-    if isinstance(Tn, DeviceField):
-        t, kind = Tn.t, 'field'
-    elif isinstance(Tn, torch.Tensor):
-        t, kind = Tn.to(device=_device(), dtype=torch.float64).contiguous(), 'torch'
-    else:
-        t, kind = _upload(np.asarray(Tn), torch.float64), 'numpy'   # fp32 fields are up-cast (waam --precision float32)
-    assert tuple(t.shape) == grid.shape
-    return t, kind
+    """-> (device tensor in the grid's layout, kind) with kind in {'numpy', 'field', 'torch'}"""
+    kind = 'field' if isinstance(Tn, DeviceField) else ('torch' if isinstance(Tn, torch.Tensor) else 'numpy')
+    if kind == 'numpy':
+        Tn = np.asarray(Tn)
+    assert tuple(Tn.shape) == grid.shape
+    return grid.layout.to_layout(Tn, torch.float64), kind
 
 
 def _wrap(t, kind):
@@ -355,26 +396,27 @@ def _wrap(t, kind):
         return DeviceField(t)
     if kind == 'torch':
         return t
-    return t.cpu().numpy()
+    return t.cpu().contiguous().numpy()
 
 
 def adi_explicit_rhs(Tn, grid, mat, params):
     """R0 of adi3d_numba_coeff.py:292-298 (stage entry point for per-stage parity tests / benchmarks)."""
     t, kind = _as_state(Tn, grid)
     kappa, _ = _gam(grid, mat, params)
-    out = torch.empty_like(t)
-    check(lib.adi_explicit_rhs(_p(t), _p(grid.d_flags), grid.nx, grid.ny, grid.nz, grid.dx, params.dt, kappa,
-                               params.theta, _p(out), _stream()))
+    out = grid.layout.empty()
+    check(lib.adi_explicit_rhs(_p(t), _p(grid.d_flags), grid.nx, grid.ny, grid.nz, grid.sx, grid.dx, params.dt,
+                               kappa, params.theta, _p(out), _stream()))
     return _wrap(out, kind)
 
 
-def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None):
+def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None, xlo=None, xhi=None):
     _, gam = _gam(grid, mat, params)
     _, work, wb = grid.scratch(2)
     v = pack.variant if variant is None else variant
     check(lib.adi_sweep(axis, v, _p(t_in), _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
-                        _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz,
-                        params.theta, gam, params.dt, float(Tinf), _p(t_out), _p(work), wb, _stream()))
+                        _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
+                        params.theta, gam, params.dt, float(Tinf), _p(t_out), _p(xlo), _p(xhi),
+                        _p(work), wb, _stream()))
 
 
 def adi_sweep_axis(axis, stage_in, grid, mat, params, pack, Tinf=0.0, variant=None):
@@ -384,19 +426,20 @@ def adi_sweep_axis(axis, stage_in, grid, mat, params, pack, Tinf=0.0, variant=No
     t, kind = _as_state(stage_in, grid)
     if variant == _lib.SWEEP_GENERAL or (variant is None and pack.variant == _lib.SWEEP_GENERAL):
         _ensure_general(pack)
-    out = torch.empty_like(t)
+    out = grid.layout.empty()
     _sweep_into(axis, t, out, grid, mat, params, pack, Tinf, variant)
     return _wrap(out, kind)
 
 
 def _ensure_general(pack):
     """materialise the arrays a forced general-pack sweep reads (zeros, like the reference's packs)"""
+    L = pack.layout
     if pack.d_dir_mask is None:
-        pack.d_dir_mask = torch.zeros(tuple(pack.d_coeff.shape), dtype=torch.uint8, device=pack.d_coeff.device)
+        pack.d_dir_mask = L.empty(torch.uint8, zero=True)
     if pack.d_dir_val is None:
-        pack.d_dir_val = torch.zeros_like(pack.d_coeff)
+        pack.d_dir_val = L.empty(zero=True)
     if pack.d_qflux is None:
-        pack.d_qflux = torch.zeros_like(pack.d_coeff)
+        pack.d_qflux = L.empty(zero=True)
 
 
 def adi_step_hip_coeff(Tn, grid, mat, params, packs, Tinf=0.0):
@@ -407,9 +450,9 @@ def adi_step_hip_coeff(Tn, grid, mat, params, packs, Tinf=0.0):
     packx, packy, packz = packs
     (ta, tb), _, _ = grid.scratch(2)
     kappa, _ = _gam(grid, mat, params)
-    out = torch.empty_like(t)
-    check(lib.adi_explicit_rhs(_p(t), _p(grid.d_flags), grid.nx, grid.ny, grid.nz, grid.dx, params.dt, kappa,
-                               params.theta, _p(ta), _stream()))
+    out = grid.layout.empty()
+    check(lib.adi_explicit_rhs(_p(t), _p(grid.d_flags), grid.nx, grid.ny, grid.nz, grid.sx, grid.dx, params.dt,
+                               kappa, params.theta, _p(ta), _stream()))
     _sweep_into(0, ta, tb, grid, mat, params, packx, Tinf)
     _sweep_into(1, tb, ta, grid, mat, params, packy, Tinf)
     _sweep_into(2, ta, out, grid, mat, params, packz, Tinf)
@@ -441,13 +484,13 @@ class StagedStepper:
 
     def step(self, T, events=None):
         g, prm = self.grid, self.params
-        t = T.t
+        t = g.layout.to_layout(T, torch.float64)
         (ta, tb), _, _ = g.scratch(2)
         kappa, _ = _gam(g, self.mat, prm)
-        out = torch.empty_like(t)
+        out = g.layout.empty()
         if events is not None:
             events[0].record()
-        check(lib.adi_explicit_rhs(_p(t), _p(g.d_flags), g.nx, g.ny, g.nz, g.dx, prm.dt, kappa, prm.theta,
+        check(lib.adi_explicit_rhs(_p(t), _p(g.d_flags), g.nx, g.ny, g.nz, g.sx, g.dx, prm.dt, kappa, prm.theta,
                                    _p(ta), _stream()))
         if events is not None:
             events[1].record()

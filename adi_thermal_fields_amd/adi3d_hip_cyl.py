@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import lib, check
-from .adi3d_hip_coeff import DeviceField, to_device, _device, _stream, _p, _upload, _wrap
+from .adi3d_hip_coeff import DeviceField, Layout, to_device, _device, _stream, _p, _wrap
 
 __all__ = ['GridCyl', 'Material', 'Params', 'RobinR', 'ZBC', 'adi_step', 'adi_step_masked', 'DeviceField', 'to_device']
 
@@ -29,6 +29,7 @@ class GridCyl:  # adi3d_cyl_phi_v3.py:33-43
         self.r_imh = self.r - 0.5 * self.dr
         self.r_iph = self.r + 0.5 * self.dr
         self.r_outer_face = self.r_iph[-1]
+        self.layout = Layout(self.nr, self.nphi, self.nz)
         self._plans = {}
         self._scratch = None
 
@@ -38,7 +39,7 @@ class GridCyl:  # adi3d_cyl_phi_v3.py:33-43
 
     def scratch(self):
         if self._scratch is None or self._scratch[0].device != _device():
-            self._scratch = [torch.empty(self.shape, dtype=torch.float64, device=_device()) for _ in range(2)]
+            self._scratch = [self.layout.empty() for _ in range(2)]
         return self._scratch
 
 
@@ -93,7 +94,7 @@ def _plan(grid, mat, dt, robin_r, zbc):
     if pl is None:
         _device()
         h = ctypes.c_void_p()
-        check(lib.adi_cyl_plan_create(grid.nr, grid.nphi, grid.nz, grid.dr, grid.dphi, grid.dz, mat.rho, mat.cp,
+        check(lib.adi_cyl_plan_create(grid.nr, grid.nphi, grid.nz, grid.layout.sx, grid.dr, grid.dphi, grid.dz, mat.rho, mat.cp,
                                       mat.k, dt, robin_r.h, robin_r.T_inf, _lib.ZBC_KINDS[zbc.kind_bot],
                                       _lib.ZBC_KINDS[zbc.kind_top], zbc.h_bot, zbc.h_top, zbc.T_inf_bot,
                                       zbc.T_inf_top, zbc.T_bot, zbc.T_top, ctypes.byref(h)))
@@ -105,14 +106,11 @@ def _plan(grid, mat, dt, robin_r, zbc):
 
 
 def _state(Tn, grid):
-    if isinstance(Tn, DeviceField):
-        t, kind = Tn.t, 'field'
-    elif isinstance(Tn, torch.Tensor):
-        t, kind = Tn.to(device=_device(), dtype=torch.float64).contiguous(), 'torch'
-    else:
-        t, kind = _upload(np.asarray(Tn), torch.float64), 'numpy'
-    assert tuple(t.shape) == grid.shape
-    return t, kind
+    kind = 'field' if isinstance(Tn, DeviceField) else ('torch' if isinstance(Tn, torch.Tensor) else 'numpy')
+    if kind == 'numpy':
+        Tn = np.asarray(Tn)
+    assert tuple(Tn.shape) == grid.shape
+    return grid.layout.to_layout(Tn, torch.float64), kind
 
 
 def _run(Tn, grid, mat, prm, robin_r, zbc, S, active, T_void, T_inner):
@@ -122,9 +120,9 @@ def _run(Tn, grid, mat, prm, robin_r, zbc, S, active, T_void, T_inner):
     t, kind = _state(Tn, grid)
     pl = _plan(grid, mat, prm.dt, robin_r, zbc)
     ta, tb = grid.scratch()
-    out = torch.empty_like(t)
-    d_S = None if S is None else _upload(S, torch.float64)
-    d_act = None if active is None else _upload(active, torch.uint8)
+    out = grid.layout.empty()
+    d_S = None if S is None else grid.layout.to_layout(S, torch.float64)
+    d_act = None if active is None else grid.layout.to_layout(active, torch.uint8)
     check(lib.adi_cyl_step(pl.handle, _p(t), _p(out), _p(ta), _p(tb), _p(d_S), _p(d_act),
                            float(T_void), float(T_inner), _stream()))
     return _wrap(out, kind)

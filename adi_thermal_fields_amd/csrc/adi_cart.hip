@@ -9,6 +9,12 @@
 //                       (sweep_axis0/1/2, adi3d_numba_coeff.py:133-237, in the full-length
 //                        identity-row form of adi3d_gpu_coeff.py:154-191)
 //   K4 k_sweep_generic  thread-per-line Thomas with HBM scratch for lines longer than 1024 rows
+//   K5 k_condense_*     slab condensation + k_interface: the reduced interface system of a sweep whose
+//                       lines span several GPUs (slab decomposition along memory axis 0)
+//
+// Device layout: planes (fixed first index) may be padded: `sx` = plane stride in elements >= ny*nz.
+// A power-of-two plane stride (512^2 doubles = 2 MiB) puts all rows of an axis-0 tile on the same HBM
+// channels (measured: 2.7 -> 4.1 TB/s on the axis-0 sweep when the stride is padded by one row).
 //
 // Data layout: C-order (n0, n1, n2) fp64 fields and 1-byte masks, exactly the reference's
 // (adi3d_numba_coeff.py:18, :31-36); axis 2 is contiguous.  All kernels are HBM-bandwidth bound
@@ -110,19 +116,27 @@ __device__ __forceinline__ void load_bytes_contig(const uint8_t *__restrict__ p,
     }
 }
 
+struct Lay {
+    int nx, ny, nz;
+    long sx;   // plane stride in elements (>= ny*nz); row stride is nz
+};
+
 template <int M, bool VEC, bool HAS_DIR, bool HAS_Q>
 __global__ __launch_bounds__(256) void k_sweep_contig(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    double *__restrict__ out, long nlines, int n, int Lp, SweepScal s)
+    double *__restrict__ out, Lay L, int Lp, SweepScal s)
 {
+    const int n = L.nz;
+    const long nlines = (long)L.nx * L.ny;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lw = 64 / Lp;  // lines per wave
     const int li = lane & (Lp - 1);
     const long line = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * lw + (lane / Lp);
     const bool active = line < nlines;
     const int r0 = li * M;
-    const long base = line * (long)n + r0;
+    const long pi = line / L.ny;
+    const long base = pi * L.sx + (line - pi * L.ny) * (long)n + r0;
 
     double vin[M], vco[M], vdv[M], vq[M];
     load_rows_contig<M, VEC>(in, base, r0, n, active, vin);
@@ -166,18 +180,73 @@ __global__ __launch_bounds__(256) void k_sweep_contig(
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: strided-axis sweep.  A workgroup owns a tile of LINES adjacent lines (LINES*8 B contiguous per
-// row: full 128-byte lines for LINES = 16) and all Lp segments of each; thread (s, kk) keeps the M rows
-// of segment s of line kk in registers (lanes run along the contiguous direction, so every access is
-// coalesced without a transpose).  Only the 7 condensation numbers per segment travel through LDS to
-// regroup the separator system line-major for the in-wave PCR, and the separator values travel back.
+// K2: strided-axis sweep.  A workgroup owns a tile of LINES adjacent lines and all Lp segments of each;
+// thread (sg, kk) keeps the M rows of segment sg of line kk in registers (lanes run along the contiguous
+// direction, so every access is coalesced without a transpose).  Only the 7 condensation numbers per
+// segment travel through LDS to regroup the separator system line-major for the in-wave PCR, and the
+// separator values travel back.  LINES = 8 (64-byte row pieces, 512-thread workgroups, two per CU so one
+// loads while the other solves); the XCD-chunked tile order puts the tile holding the other half of each
+// 128-byte line on the same XCD right behind it, so the half-line is served by that XCD's L2.
+//
+// Lines geometry: element (row r, line (to, kcol)) lives at to*outer_stride + r*stride + kcol.
+// xlo/xhi (optional, dense per line): values of the unknown just before row 0 / after row n-1 when the line
+// continues on a neighbouring GPU; the coupling itself comes from the halo bits of `flags`.
 // ------------------------------------------------------------------------------------------------
+struct LineGeom {
+    int n;              // rows per line
+    long stride;        // elements between consecutive rows
+    int n_inner;        // lines that are contiguous in memory (stride 1)
+    long n_outer;       // groups of n_inner lines
+    long outer_stride;  // elements between groups
+    int lbit;           // flags bit of the "previous row in mask" test (next row: lbit + 1)
+};
+
+template <int M, bool HAS_DIR, bool HAS_Q>
+__device__ __forceinline__ void load_segment_strided(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    const LineGeom &g, long base, int r0, bool active, const SweepScal &s,
+    const double *__restrict__ xlo, const double *__restrict__ xhi, long line_id,
+    double (&a)[M], double (&b)[M], double (&c)[M], double (&d)[M])
+{
+    double vin[M], vco[M], vdv[M], vq[M];
+    unsigned fb[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        const bool ok = active && (r0 + r) < g.n;
+        const long p = base + (long)(r0 + r) * g.stride;
+        fb[r] = ok ? flags[p] : 0u;
+        vin[r] = ok ? in[p] : 0.0;
+        vco[r] = ok ? coeff[p] : 0.0;
+        if (HAS_DIR) vdv[r] = ok ? dval[p] : 0.0;
+        if (HAS_Q) vq[r] = ok ? qf[p] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        bool dir = false;
+        if (HAS_DIR) dir = active && (r0 + r) < g.n && dmask[base + (long)(r0 + r) * g.stride] != 0;
+        assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> g.lbit) & 1u, (fb[r] >> (g.lbit + 1)) & 1u, dir, vin[r],
+                                     vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r], c[r], d[r]);
+    }
+    // line ends: fold the coupling to the neighbouring GPU's row into the right-hand side
+    if (r0 == 0) {
+        if (xlo != nullptr && active) d[0] = __builtin_fma(-a[0], xlo[line_id], d[0]);
+        a[0] = 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+        if (r0 + r == g.n - 1) {
+            if (xhi != nullptr && active) d[r] = __builtin_fma(-c[r], xhi[line_id], d[r]);
+            c[r] = 0.0;
+        }
+}
+
 template <int M, bool HAS_DIR, bool HAS_Q>
 __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    double *__restrict__ out, int n, long stride, int n_inner, long outer_stride, int Lp, int LINES,
-    int tiles_inner, long ntiles, int lbit, SweepScal s)
+    double *__restrict__ out, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
+    const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s)
 {
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x;
@@ -186,32 +255,13 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
     const int ti = (int)(tile - to * tiles_inner);
     const int kk = tid % LINES, sg = tid / LINES;
     const int kcol = ti * LINES + kk;
-    const bool active = kcol < n_inner;
-    const long base = to * outer_stride + kcol;
+    const bool active = kcol < g.n_inner;
+    const long base = to * g.outer_stride + kcol;
     const int r0 = sg * M;
 
     double a[M], b[M], c[M], d[M];
-    {
-        double vin[M], vco[M], vdv[M], vq[M];
-        unsigned fb[M];
-#pragma unroll
-        for (int r = 0; r < M; ++r) {
-            const bool ok = active && (r0 + r) < n;
-            const long p = base + (long)(r0 + r) * stride;
-            fb[r] = ok ? flags[p] : 0u;
-            vin[r] = ok ? in[p] : 0.0;
-            vco[r] = ok ? coeff[p] : 0.0;
-            if (HAS_DIR) vdv[r] = ok ? dval[p] : 0.0;
-            if (HAS_Q) vq[r] = ok ? qf[p] : 0.0;
-        }
-#pragma unroll
-        for (int r = 0; r < M; ++r) {
-            bool dir = false;
-            if (HAS_DIR) dir = active && (r0 + r) < n && dmask[base + (long)(r0 + r) * stride] != 0;
-            assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> lbit) & 1u, (fb[r] >> (lbit + 1)) & 1u, dir, vin[r],
-                                         vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r], c[r], d[r]);
-        }
-    }
+    load_segment_strided<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, xlo, xhi,
+                                            to * (long)g.n_inner + kcol, a, b, c, d);
 
     double ip[M - 1];
     Cond k;
@@ -253,7 +303,164 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
     back_solve<M>(a, c, d, ip, xL, xS, x);
 #pragma unroll
     for (int r = 0; r < M; ++r)
-        if (active && (r0 + r) < n) out[base + (long)(r0 + r) * stride] = x[r];
+        if (active && (r0 + r) < g.n) out[base + (long)(r0 + r) * g.stride] = x[r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5a: slab condensation (pass A of a sweep whose lines continue on neighbouring GPUs).  Same loads and
+// per-thread work as K2's phase 1, but every thread condenses ALL its M rows and the Lp blocks of a line
+// are merged by an ordered tree reduction; lane 0 writes the six numbers that describe the slab's part of
+// the line to its neighbours:  x_first = gF - aF*xl - cF*xr,  x_last = gL - aL*xl - cL*xr.
+// Requires n % M == 0 (whole segments).  cond: [6][nlines] dense.
+// ------------------------------------------------------------------------------------------------
+template <int M, bool HAS_DIR, bool HAS_Q>
+__global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_condense_strided(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ cond, long nlines, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
+    SweepScal s)
+{
+    extern __shared__ __align__(16) double sm[];
+    const int tid = threadIdx.x;
+    const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
+    const long to = tile / tiles_inner;
+    const int ti = (int)(tile - to * tiles_inner);
+    const int kk = tid % LINES, sg = tid / LINES;
+    const int kcol = ti * LINES + kk;
+    const bool active = kcol < g.n_inner;
+    const long base = to * g.outer_stride + kcol;
+    const int r0 = sg * M;
+
+    double a[M], b[M], c[M], d[M];
+    {
+        // same assembly as the solve pass, but the end couplings stay in a[0] / c[n-1] (they are the
+        // aF, aL / cF, cL of the slab)
+        double vin[M], vco[M], vdv[M], vq[M];
+        unsigned fb[M];
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            const bool ok = active && (r0 + r) < g.n;
+            const long p = base + (long)(r0 + r) * g.stride;
+            fb[r] = ok ? flags[p] : 0u;
+            vin[r] = ok ? in[p] : 0.0;
+            vco[r] = ok ? coeff[p] : 0.0;
+            if (HAS_DIR) vdv[r] = ok ? dval[p] : 0.0;
+            if (HAS_Q) vq[r] = ok ? qf[p] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            bool dir = false;
+            if (HAS_DIR) dir = active && (r0 + r) < g.n && dmask[base + (long)(r0 + r) * g.stride] != 0;
+            assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> g.lbit) & 1u, (fb[r] >> (g.lbit + 1)) & 1u, dir,
+                                         vin[r], vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r],
+                                         c[r], d[r]);
+        }
+    }
+    Cond k;
+    condense_full<M>(a, b, c, d, k);
+
+    const int ld = Lp + 1;
+    const int plane = LINES * ld;
+    {
+        const int w = kk * ld + sg;
+        sm[w] = k.gF; sm[plane + w] = k.aF; sm[2 * plane + w] = k.cF;
+        sm[3 * plane + w] = k.gL; sm[4 * plane + w] = k.aL; sm[5 * plane + w] = k.cL;
+    }
+    __syncthreads();
+    const int pl = tid / Lp, ps = tid - pl * Lp;
+    const int w = pl * ld + ps;
+    Cond q;
+    q.gF = sm[w]; q.aF = sm[plane + w]; q.cF = sm[2 * plane + w];
+    q.gL = sm[3 * plane + w]; q.aL = sm[4 * plane + w]; q.cL = sm[5 * plane + w];
+    q = reduce_cond(q, ps, Lp, g.n / M);
+    const int kc2 = ti * LINES + pl;
+    if (ps == 0 && kc2 < g.n_inner) {
+        const long id = to * (long)g.n_inner + kc2;
+        cond[id] = q.gF; cond[nlines + id] = q.aF; cond[2 * nlines + id] = q.cF;
+        cond[3 * nlines + id] = q.gL; cond[4 * nlines + id] = q.aL; cond[5 * nlines + id] = q.cL;
+    }
+}
+
+// K5b: generic slab condensation, one thread per line, two serial recurrences (any n; reads rows twice).
+template <bool HAS_DIR, bool HAS_Q>
+__global__ __launch_bounds__(256) void k_condense_generic(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ cond, long nlines, LineGeom g, long inner_stride, SweepScal s)
+{
+    const long lid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lid >= nlines) return;
+    const long o = lid / g.n_inner, kc = lid - o * g.n_inner;
+    const long base = o * g.outer_stride + kc * inner_stride;
+    const int n = g.n;
+    double a0 = 0.0, cn = 0.0;
+    // top-down: last component of B^-1 d, B^-1 e_0 ; 1/pivot_last
+    double ip = 0.0, y = 0.0, e = 1.0, cprev = 0.0;
+    for (int r = 0; r < n; ++r) {
+        const long p = base + (long)r * g.stride;
+        const unsigned f = flags[p];
+        double a, b, c, d;
+        assemble_row<HAS_DIR, HAS_Q>(f & 1u, (f >> g.lbit) & 1u, (f >> (g.lbit + 1)) & 1u, HAS_DIR && dmask[p] != 0,
+                                     in[p], coeff[p], HAS_DIR ? dval[p] : 0.0, HAS_Q ? qf[p] : 0.0, s, a, b, c, d);
+        if (r == 0) { a0 = a; ip = 1.0 / b; y = d; }
+        else { const double w = a * ip; ip = 1.0 / (b - w * cprev); y = d - w * y; e = -w * e; }
+        cprev = c;
+        if (r == n - 1) cn = c;
+    }
+    const double gL = y * ip, aL = a0 * (e * ip), cL = cn * ip;
+    // bottom-up
+    double jp = 0.0, z = 0.0, f2 = 1.0, anext = 0.0;
+    for (int r = n - 1; r >= 0; --r) {
+        const long p = base + (long)r * g.stride;
+        const unsigned f = flags[p];
+        double a, b, c, d;
+        assemble_row<HAS_DIR, HAS_Q>(f & 1u, (f >> g.lbit) & 1u, (f >> (g.lbit + 1)) & 1u, HAS_DIR && dmask[p] != 0,
+                                     in[p], coeff[p], HAS_DIR ? dval[p] : 0.0, HAS_Q ? qf[p] : 0.0, s, a, b, c, d);
+        if (r == n - 1) { jp = 1.0 / b; z = d; }
+        else { const double w = c * jp; jp = 1.0 / (b - w * anext); z = d - w * z; f2 = -w * f2; }
+        anext = a;
+    }
+    cond[lid] = z * jp; cond[nlines + lid] = a0 * jp; cond[2 * nlines + lid] = cn * (f2 * jp);
+    cond[3 * nlines + lid] = gL; cond[4 * nlines + lid] = aL; cond[5 * nlines + lid] = cL;
+}
+
+// K5c: interface solve.  cond_all: [nranks][6][nlines] (all-gathered).  For this rank, merge the slabs below
+// and above it, solve the 2x2 system for its own first/last unknown and emit the neighbours' boundary
+// values: xlo = last unknown of the slab below, xhi = first unknown of the slab above.
+__global__ __launch_bounds__(256) void k_interface(const double *__restrict__ cond_all, int nranks, int rank,
+                                                   long nlines, double *__restrict__ xlo, double *__restrict__ xhi)
+{
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nlines) return;
+    auto ld = [&](int r) {
+        const double *q = cond_all + (long)r * 6 * nlines + id;
+        Cond k;
+        k.gF = q[0]; k.aF = q[nlines]; k.cF = q[2 * nlines]; k.gL = q[3 * nlines]; k.aL = q[4 * nlines];
+        k.cL = q[5 * nlines];
+        return k;
+    };
+    const Cond C = ld(rank);
+    Cond P = {0, 0, 0, 0, 0, 0}, S = {0, 0, 0, 0, 0, 0};   // empty neighbours: decoupled zeros
+    if (rank > 0) {
+        P = ld(0);
+        for (int r = 1; r < rank; ++r) P = merge_cond(P, ld(r));
+    }
+    if (rank < nranks - 1) {
+        S = ld(nranks - 1);
+        for (int r = nranks - 2; r > rank; --r) S = merge_cond(ld(r), S);
+    }
+    // unknowns f = x_first(C), l = x_last(C);  x_last(P) = P.gL - P.cL f ;  x_first(S) = S.gF - S.aF l
+    //   f = C.gF - C.aF (P.gL - P.cL f) - C.cF (S.gF - S.aF l)
+    //   l = C.gL - C.aL (P.gL - P.cL f) - C.cL (S.gF - S.aF l)
+    const double m00 = 1.0 - C.aF * P.cL, m01 = -C.cF * S.aF;
+    const double m10 = -C.aL * P.cL, m11 = 1.0 - C.cL * S.aF;
+    const double r0 = C.gF - C.aF * P.gL - C.cF * S.gF;
+    const double r1 = C.gL - C.aL * P.gL - C.cL * S.gF;
+    const double idet = 1.0 / (m00 * m11 - m01 * m10);
+    const double f = (r0 * m11 - m01 * r1) * idet;
+    const double l = (m00 * r1 - m10 * r0) * idet;
+    xlo[id] = P.gL - P.cL * f;
+    xhi[id] = S.gF - S.aF * l;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -264,20 +471,23 @@ template <bool HAS_DIR, bool HAS_Q>
 __global__ __launch_bounds__(256) void k_sweep_generic(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    double *__restrict__ out, int n, long stride, long n_inner, long inner_stride, long n_outer,
-    long outer_stride, int lbit, double *__restrict__ wc, double *__restrict__ wd, SweepScal s)
+    double *__restrict__ out, LineGeom g, long inner_stride, const double *__restrict__ xlo,
+    const double *__restrict__ xhi, double *__restrict__ wc, double *__restrict__ wd, SweepScal s)
 {
     const long lid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (lid >= n_inner * n_outer) return;
-    const long o = lid / n_inner, kc = lid - o * n_inner;
-    const long base = o * outer_stride + kc * inner_stride;
+    if (lid >= (long)g.n_inner * g.n_outer) return;
+    const long o = lid / g.n_inner, kc = lid - o * g.n_inner;
+    const long base = o * g.outer_stride + kc * inner_stride;
+    const int n = g.n;
     double cp = 0.0, dp = 0.0;
     for (int r = 0; r < n; ++r) {
-        const long p = base + (long)r * stride;
+        const long p = base + (long)r * g.stride;
         const unsigned f = flags[p];
         double a, b, c, d;
-        assemble_row<HAS_DIR, HAS_Q>(f & 1u, (f >> lbit) & 1u, (f >> (lbit + 1)) & 1u, HAS_DIR && dmask[p] != 0, in[p],
+        assemble_row<HAS_DIR, HAS_Q>(f & 1u, (f >> g.lbit) & 1u, (f >> (g.lbit + 1)) & 1u, HAS_DIR && dmask[p] != 0, in[p],
                                      coeff[p], HAS_DIR ? dval[p] : 0.0, HAS_Q ? qf[p] : 0.0, s, a, b, c, d);
+        if (r == 0) { if (xlo != nullptr) d -= a * xlo[lid]; a = 0.0; }
+        if (r == n - 1) { if (xhi != nullptr) d -= c * xhi[lid]; c = 0.0; }
         const double inv = 1.0 / (b - a * cp);
         cp = c * inv;
         dp = (d - a * dp) * inv;
@@ -286,7 +496,7 @@ __global__ __launch_bounds__(256) void k_sweep_generic(
     }
     double x = 0.0;
     for (int r = n - 1; r >= 0; --r) {
-        const long p = base + (long)r * stride;
+        const long p = base + (long)r * g.stride;
         x = wd[p] - wc[p] * x;
         out[p] = x;
     }
@@ -316,10 +526,11 @@ __device__ __forceinline__ double lap_axis(bool lo, bool hi, double tlo, double 
 constexpr int kExplicitJR = 8;
 
 __global__ __launch_bounds__(256) void k_explicit_v2(const double *__restrict__ T, const uint8_t *__restrict__ flags,
-                                                     double *__restrict__ R0, int nx, int ny, int nz,
-                                                     double invdx2, double f, int jslab, int ktiles, long ntiles)
+                                                     double *__restrict__ R0, Lay L, double invdx2, double f,
+                                                     int jslab, int ktiles, long ntiles)
 {
 #pragma clang fp contract(off)
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
     const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
     const int jc_per_slab = (jslab + kExplicitJR - 1) / kExplicitJR;
     const long per_plane = (long)jc_per_slab * ktiles;
@@ -336,7 +547,7 @@ __global__ __launch_bounds__(256) void k_explicit_v2(const double *__restrict__ 
     const int k0 = kt * 512 + 2 * (int)threadIdx.x;
     const bool kin = k0 < nz;            // nz is even: both cells of the pair are inside
     const int lane = threadIdx.x & 63;
-    const long sx = (long)ny * nz, sy = nz;
+    const long sx = L.sx, sy = nz;
     if (jbeg >= jend) return;
     long p = (long)i * sx + (long)jbeg * sy + k0;
     const double2 zero2 = make_double2(0.0, 0.0);
@@ -384,16 +595,28 @@ __global__ __launch_bounds__(256) void k_explicit_v2(const double *__restrict__ 
     }
 }
 
+// cell index -> (i, j, k, memory offset) for elementwise kernels over a padded-plane layout
+__device__ __forceinline__ bool cell_of(long q, const Lay &L, int &i, int &j, int &k, long &p)
+{
+    const long plane = (long)L.ny * L.nz;
+    if (q >= plane * L.nx) return false;
+    i = (int)(q / plane);
+    const long r = q - (long)i * plane;
+    j = (int)(r / L.nz);
+    k = (int)(r - (long)j * L.nz);
+    p = (long)i * L.sx + r;
+    return true;
+}
+
 // generic form (odd nz or unaligned views): one cell per thread
 __global__ __launch_bounds__(256) void k_explicit(const double *__restrict__ T, const uint8_t *__restrict__ flags,
-                                                  double *__restrict__ R0, int nx, int ny, int nz,
-                                                  double invdx2, double f)
+                                                  double *__restrict__ R0, Lay L, double invdx2, double f)
 {
 #pragma clang fp contract(off)
-    const long N = (long)nx * ny * nz;
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= N) return;
-    const long sx = (long)ny * nz, sy = nz;
+    int i, j, k;
+    long p;
+    if (!cell_of((long)blockIdx.x * blockDim.x + threadIdx.x, L, i, j, k, p)) return;
+    const long sx = L.sx, sy = L.nz;
     const double t = T[p];
     const unsigned fl = flags[p];
     double L0 = 0.0, L1 = 0.0, L2 = 0.0;
@@ -408,25 +631,21 @@ __global__ __launch_bounds__(256) void k_explicit(const double *__restrict__ T, 
 // neighbour flags: bit0 = cell in mask, bit(1 + 2*axis) / bit(2 + 2*axis) = the minus / plus neighbour along
 // `axis` exists and is in the mask.  Derived from the mask whenever it changes (the mask "folds into the
 // coefficient build on device"); halo planes of a slab decomposition are simply part of the mask array.
-__global__ __launch_bounds__(256) void k_build_flags(const uint8_t *__restrict__ mask, int nx, int ny, int nz,
-                                                     uint8_t *__restrict__ flags)
+__global__ __launch_bounds__(256) void k_build_flags(const uint8_t *__restrict__ mask, Lay L, uint8_t *__restrict__ flags)
 {
-    const long N = (long)nx * ny * nz;
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= N) return;
-    const int k = (int)(p % nz);
-    const long ij = p / nz;
-    const int j = (int)(ij % ny), i = (int)(ij / ny);
-    const long sx = (long)ny * nz, sy = nz;
+    int i, j, k;
+    long p;
+    if (!cell_of((long)blockIdx.x * blockDim.x + threadIdx.x, L, i, j, k, p)) return;
+    const long sx = L.sx, sy = L.nz;
     unsigned f = 0;
     if (mask[p]) {
         f = 1u;
         if (i > 0 && mask[p - sx]) f |= 2u;
-        if (i + 1 < nx && mask[p + sx]) f |= 4u;
+        if (i + 1 < L.nx && mask[p + sx]) f |= 4u;
         if (j > 0 && mask[p - sy]) f |= 8u;
-        if (j + 1 < ny && mask[p + sy]) f |= 16u;
+        if (j + 1 < L.ny && mask[p + sy]) f |= 16u;
         if (k > 0 && mask[p - 1]) f |= 32u;
-        if (k + 1 < nz && mask[p + 1]) f |= 64u;
+        if (k + 1 < L.nz && mask[p + 1]) f |= 64u;
     }
     flags[p] = (uint8_t)f;
 }
@@ -441,21 +660,18 @@ struct FaceSpec {
     const double *field[6];
 };
 
-__global__ __launch_bounds__(256) void k_build_coeffs(const uint8_t *__restrict__ mask, int nx, int ny, int nz,
-                                                      double A, double Ccell, FaceSpec h, FaceSpec q,
-                                                      double *__restrict__ c0, double *__restrict__ c1,
-                                                      double *__restrict__ c2, double *__restrict__ q0,
-                                                      double *__restrict__ q1, double *__restrict__ q2)
+__global__ __launch_bounds__(256) void k_build_coeffs(const uint8_t *__restrict__ mask, Lay L, double A, double Ccell,
+                                                      FaceSpec h, FaceSpec q, double *__restrict__ c0,
+                                                      double *__restrict__ c1, double *__restrict__ c2,
+                                                      double *__restrict__ q0, double *__restrict__ q1,
+                                                      double *__restrict__ q2)
 {
 #pragma clang fp contract(off)
-    const long N = (long)nx * ny * nz;
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= N) return;
-    const int k = (int)(p % nz);
-    const long ij = p / nz;
-    const int j = (int)(ij % ny), i = (int)(ij / ny);
-    const long st[3] = {(long)ny * nz, (long)nz, 1};
-    const int pos[3] = {i, j, k}, nn[3] = {nx, ny, nz};
+    int i, j, k;
+    long p;
+    if (!cell_of((long)blockIdx.x * blockDim.x + threadIdx.x, L, i, j, k, p)) return;
+    const long st[3] = {L.sx, (long)L.nz, 1};
+    const int pos[3] = {i, j, k}, nn[3] = {L.nx, L.ny, L.nz};
     const bool m = mask[p] != 0;
     double co[3] = {0.0, 0.0, 0.0}, qq[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -479,17 +695,14 @@ __global__ __launch_bounds__(256) void k_build_coeffs(const uint8_t *__restrict_
     q0[p] = qq[0]; q1[p] = qq[1]; q2[p] = qq[2];
 }
 
-__global__ __launch_bounds__(256) void k_exposed(const uint8_t *__restrict__ mask, int nx, int ny, int nz,
-                                                 int face, uint8_t *__restrict__ out)
+__global__ __launch_bounds__(256) void k_exposed(const uint8_t *__restrict__ mask, Lay L, int face,
+                                                 uint8_t *__restrict__ out)
 {
-    const long N = (long)nx * ny * nz;
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= N) return;
-    const int k = (int)(p % nz);
-    const long ij = p / nz;
-    const int j = (int)(ij % ny), i = (int)(ij / ny);
-    const long st[3] = {(long)ny * nz, (long)nz, 1};
-    const int pos[3] = {i, j, k}, nn[3] = {nx, ny, nz};
+    int i, j, k;
+    long p;
+    if (!cell_of((long)blockIdx.x * blockDim.x + threadIdx.x, L, i, j, k, p)) return;
+    const long st[3] = {L.sx, (long)L.nz, 1};
+    const int pos[3] = {i, j, k}, nn[3] = {L.nx, L.ny, L.nz};
     const int ax = face >> 1;
     const bool m = mask[p] != 0;
     const int nbp = pos[ax] + ((face & 1) ? 1 : -1);
@@ -515,8 +728,7 @@ __global__ __launch_bounds__(256) void k_mask_or(uint8_t *__restrict__ dst, cons
 // ------------------------------------------------------------------------------------------------
 // host-side launch logic
 // ------------------------------------------------------------------------------------------------
-// lines per strided tile (8 B * lines contiguous per row).  16 = whole 128-byte lines; ADI_STRIDED_LINES
-// overrides for tuning runs.
+// lines per strided tile (8 B * lines contiguous per row); ADI_STRIDED_LINES overrides for tuning runs.
 static int strided_lines_pref()
 {
     static int v = 0;
@@ -531,89 +743,150 @@ static int strided_lines_pref()
 static int contig_rows_per_lane(int n) { return n <= 128 ? 2 : (n <= 256 ? 4 : (n <= 512 ? 8 : 16)); }
 static int strided_rows_per_thread(int n) { return n <= 16 ? 2 : (n <= 32 ? 4 : (n <= 512 ? 8 : 16)); }
 
+static LineGeom line_geom(int axis, const Lay &L, long *inner_stride)
+{
+    LineGeom g;
+    g.lbit = 1 + 2 * axis;
+    if (axis == 0) { g.n = L.nx; g.stride = L.sx; g.n_inner = L.ny * L.nz; g.n_outer = 1; g.outer_stride = 0; *inner_stride = 1; }
+    else if (axis == 1) { g.n = L.ny; g.stride = L.nz; g.n_inner = L.nz; g.n_outer = L.nx; g.outer_stride = L.sx; *inner_stride = 1; }
+    else { g.n = L.nz; g.stride = 1; g.n_inner = L.ny; g.n_outer = L.nx; g.outer_stride = L.sx; *inner_stride = L.nz; }
+    return g;
+}
+
 template <int M, bool HAS_DIR, bool HAS_Q>
-static void launch_contig(const double *in, const uint8_t *mask, const double *coeff, const uint8_t *dmask,
-                          const double *dval, const double *qf, double *out, long nlines, int n, SweepScal s,
+static void launch_contig(const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
+                          const double *dval, const double *qf, double *out, const Lay &L, SweepScal s,
                           hipStream_t st)
 {
+    const int n = L.nz;
+    const long nlines = (long)L.nx * L.ny;
     const int Lp = next_pow2((n + M - 1) / M);
     const int lw = 64 / Lp;
     const long waves = (nlines + lw - 1) / lw;
     const unsigned grid = (unsigned)((waves + 3) / 4);
     const bool aligned = (((uintptr_t)in | (uintptr_t)coeff | (uintptr_t)out | (uintptr_t)dval | (uintptr_t)qf) & 15) == 0 &&
-                         (((uintptr_t)mask | (uintptr_t)dmask) & 7) == 0;
+                         (((uintptr_t)flags | (uintptr_t)dmask) & 7) == 0 && (L.sx % 8 == 0);
     const bool vec = aligned && (n % M == 0);
     if (vec)
-        hipLaunchKernelGGL((k_sweep_contig<M, true, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, mask, coeff,
-                           dmask, dval, qf, out, nlines, n, Lp, s);
+        hipLaunchKernelGGL((k_sweep_contig<M, true, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
+                           dmask, dval, qf, out, L, Lp, s);
     else
-        hipLaunchKernelGGL((k_sweep_contig<M, false, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, mask, coeff,
-                           dmask, dval, qf, out, nlines, n, Lp, s);
+        hipLaunchKernelGGL((k_sweep_contig<M, false, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
+                           dmask, dval, qf, out, L, Lp, s);
+}
+
+static void strided_tiling(int M, const LineGeom &g, int &Lp, int &lines, int &tiles_inner, long &ntiles, size_t &lds)
+{
+    Lp = next_pow2((g.n + M - 1) / M);
+    lines = (M <= 8) ? strided_lines_pref() : 8;  // M = 16 keeps 512-thread workgroups (register budget)
+    while (lines * Lp < 256) lines <<= 1;
+    tiles_inner = (g.n_inner + lines - 1) / lines;
+    ntiles = (long)tiles_inner * g.n_outer;
+    lds = (size_t)8 * lines * (Lp + 1) * sizeof(double);
 }
 
 template <int M, bool HAS_DIR, bool HAS_Q>
-static void launch_strided(const double *in, const uint8_t *mask, const double *coeff, const uint8_t *dmask,
-                           const double *dval, const double *qf, double *out, int n, long stride, int n_inner,
-                           long n_outer, long outer_stride, int lbit, SweepScal s, hipStream_t st)
+static void launch_strided(const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
+                           const double *dval, const double *qf, double *out, const LineGeom &g,
+                           const double *xlo, const double *xhi, SweepScal s, hipStream_t st)
 {
-    const int Lp = next_pow2((n + M - 1) / M);
-    int lines = (M <= 8) ? strided_lines_pref() : 8;  // M = 16 keeps 512-thread workgroups (register budget)
-    while (lines * Lp < 256) lines <<= 1;
-    const int tiles_inner = (n_inner + lines - 1) / lines;
-    const long ntiles = (long)tiles_inner * n_outer;
-    const size_t lds = (size_t)8 * lines * (Lp + 1) * sizeof(double);
+    int Lp, lines, tiles_inner;
+    long ntiles;
+    size_t lds;
+    strided_tiling(M, g, Lp, lines, tiles_inner, ntiles, lds);
     hipLaunchKernelGGL((k_sweep_strided<M, HAS_DIR, HAS_Q>), dim3((unsigned)ntiles), dim3(lines * Lp), lds, st, in,
-                       mask, coeff, dmask, dval, qf, out, n, stride, n_inner, outer_stride, Lp, lines, tiles_inner,
-                       ntiles, lbit, s);
+                       flags, coeff, dmask, dval, qf, out, g, Lp, lines, tiles_inner, ntiles, xlo, xhi, s);
+}
+
+template <int M, bool HAS_DIR, bool HAS_Q>
+static void launch_condense(const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
+                            const double *dval, const double *qf, double *cond, long nlines, const LineGeom &g,
+                            SweepScal s, hipStream_t st)
+{
+    int Lp, lines, tiles_inner;
+    long ntiles;
+    size_t lds;
+    strided_tiling(M, g, Lp, lines, tiles_inner, ntiles, lds);
+    hipLaunchKernelGGL((k_condense_strided<M, HAS_DIR, HAS_Q>), dim3((unsigned)ntiles), dim3(lines * Lp), lds, st, in,
+                       flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, lines, tiles_inner, ntiles, s);
 }
 
 template <bool HAS_DIR, bool HAS_Q>
-static int sweep_dispatch(int axis, const double *in, const uint8_t *mask, const double *coeff, const uint8_t *dmask,
-                          const double *dval, const double *qf, int nx, int ny, int nz, SweepScal s, double *out,
-                          void *work, size_t work_bytes, hipStream_t st)
+static int sweep_dispatch(int axis, const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
+                          const double *dval, const double *qf, const Lay &L, SweepScal s, double *out,
+                          const double *xlo, const double *xhi, void *work, size_t work_bytes, hipStream_t st)
 {
-    const int nn[3] = {nx, ny, nz};
-    const int n = nn[axis];
-    const long N = (long)nx * ny * nz;
-    if (n > kMaxFastLine) {
-        if (work == nullptr || work_bytes < (size_t)2 * N * sizeof(double))
-            return set_err(ADI_ERR_ARG, "adi_sweep: line length %d > %d needs a workspace of %zu bytes", n,
-                           kMaxFastLine, (size_t)2 * N * sizeof(double));
-        double *wc = (double *)work, *wd = wc + N;
-        long n_inner, inner_stride, n_outer, outer_stride, stride;
-        if (axis == 0) { n_inner = (long)ny * nz; inner_stride = 1; n_outer = 1; outer_stride = 0; stride = (long)ny * nz; }
-        else if (axis == 1) { n_inner = nz; inner_stride = 1; n_outer = nx; outer_stride = (long)ny * nz; stride = nz; }
-        else { n_inner = (long)nx * ny; inner_stride = nz; n_outer = 1; outer_stride = 0; stride = 1; }
-        const long nl = n_inner * n_outer;
+    long inner_stride;
+    const LineGeom g = line_geom(axis, L, &inner_stride);
+    const int n = g.n;
+    if (n > kMaxFastLine || (axis == 2 && (xlo || xhi))) {
+        const size_t need = (size_t)2 * L.nx * L.sx * sizeof(double);
+        if (work == nullptr || work_bytes < need)
+            return set_err(ADI_ERR_ARG, "adi_sweep: this sweep (line length %d) needs a workspace of %zu bytes", n, need);
+        double *wc = (double *)work, *wd = wc + (size_t)L.nx * L.sx;
+        const long nl = (long)g.n_inner * g.n_outer;
         hipLaunchKernelGGL((k_sweep_generic<HAS_DIR, HAS_Q>), dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, in,
-                           mask, coeff, dmask, dval, qf, out, n, stride, n_inner, inner_stride, n_outer, outer_stride,
-                           1 + 2 * axis, wc, wd, s);
+                           flags, coeff, dmask, dval, qf, out, g, inner_stride, xlo, xhi, wc, wd, s);
         return ADI_OK;
     }
     if (axis == 2) {
-        const long nlines = (long)nx * ny;
         switch (contig_rows_per_lane(n)) {
-            case 2: launch_contig<2, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, nlines, n, s, st); break;
-            case 4: launch_contig<4, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, nlines, n, s, st); break;
-            case 8: launch_contig<8, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, nlines, n, s, st); break;
-            default: launch_contig<16, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, nlines, n, s, st); break;
+            case 2: launch_contig<2, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, st); break;
+            case 4: launch_contig<4, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, st); break;
+            case 8: launch_contig<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, st); break;
+            default: launch_contig<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, st); break;
         }
     } else {
-        const long stride = (axis == 0) ? (long)ny * nz : nz;
-        const long n_inner_l = (axis == 0) ? (long)ny * nz : nz;
-        const long n_outer = (axis == 0) ? 1 : nx;
-        const long outer_stride = (axis == 0) ? 0 : (long)ny * nz;
-        if (n_inner_l > 0x7fffffffL) return set_err(ADI_ERR_UNSUPPORTED, "adi_sweep: plane too large");
-        const int n_inner = (int)n_inner_l;
         switch (strided_rows_per_thread(n)) {
-            case 2: launch_strided<2, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, n, stride, n_inner, n_outer, outer_stride, 1 + 2 * axis, s, st); break;
-            case 4: launch_strided<4, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, n, stride, n_inner, n_outer, outer_stride, 1 + 2 * axis, s, st); break;
-            case 8: launch_strided<8, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, n, stride, n_inner, n_outer, outer_stride, 1 + 2 * axis, s, st); break;
-            default: launch_strided<16, HAS_DIR, HAS_Q>(in, mask, coeff, dmask, dval, qf, out, n, stride, n_inner, n_outer, outer_stride, 1 + 2 * axis, s, st); break;
+            case 2: launch_strided<2, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, st); break;
+            case 4: launch_strided<4, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, st); break;
+            case 8: launch_strided<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, st); break;
+            default: launch_strided<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, st); break;
         }
     }
     return ADI_OK;
 }
+
+template <bool HAS_DIR, bool HAS_Q>
+static int condense_dispatch(int axis, const double *in, const uint8_t *flags, const double *coeff,
+                             const uint8_t *dmask, const double *dval, const double *qf, const Lay &L, SweepScal s,
+                             double *cond, hipStream_t st)
+{
+    long inner_stride;
+    const LineGeom g = line_geom(axis, L, &inner_stride);
+    const long nlines = (long)g.n_inner * g.n_outer;
+    const int n = g.n;
+    int M = 0;
+    if (axis != 2 && n <= kMaxFastLine) {
+        const int pref = strided_rows_per_thread(n);
+        for (int m = pref; m >= 2; m >>= 1)
+            if (n % m == 0 && n / m <= 64) { M = m; break; }
+    }
+    switch (M) {
+        case 2: launch_condense<2, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, st); break;
+        case 4: launch_condense<4, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, st); break;
+        case 8: launch_condense<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, st); break;
+        case 16: launch_condense<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, st); break;
+        default:
+            hipLaunchKernelGGL((k_condense_generic<HAS_DIR, HAS_Q>), dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0,
+                               st, in, flags, coeff, dmask, dval, qf, cond, nlines, g, inner_stride, s);
+    }
+    return ADI_OK;
+}
+
+static int make_lay(int nx, int ny, int nz, long plane_stride, Lay *L)
+{
+    if (nx <= 0 || ny <= 0 || nz <= 0) return set_err(ADI_ERR_ARG, "bad grid %d x %d x %d", nx, ny, nz);
+    const long dense = (long)ny * nz;
+    if (plane_stride != 0 && plane_stride < dense)
+        return set_err(ADI_ERR_ARG, "plane_stride %ld < ny*nz = %ld", plane_stride, dense);
+    if (dense > 0x7fffffffL) return set_err(ADI_ERR_UNSUPPORTED, "plane of %ld cells is too large", dense);
+    L->nx = nx; L->ny = ny; L->nz = nz;
+    L->sx = plane_stride ? plane_stride : dense;
+    return ADI_OK;
+}
+
+static unsigned cell_blocks(const Lay &L) { return (unsigned)(((long)L.nx * L.ny * L.nz + 255) / 256); }
 
 }  // namespace adi
 
@@ -621,24 +894,34 @@ using namespace adi;
 
 extern "C" {
 
-int adi_exposed_mask(const uint8_t *d_mask, int nx, int ny, int nz, int face, uint8_t *d_exposed, void *stream)
+long adi_recommended_plane_stride(int ny, int nz)
+{
+    // planes whose byte size is a multiple of 16 KiB alias on the HBM channel interleave when walked with
+    // that stride (axis-0 sweeps): pad by 512 elements (4 KiB keeps every plane 4 KiB-aligned).
+    const long dense = (long)ny * nz;
+    return (dense * 8 % 16384 == 0) ? dense + 512 : dense;
+}
+
+int adi_exposed_mask(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, int face, uint8_t *d_exposed,
+                     void *stream)
 {
     ADI_REQUIRE(face >= 0 && face < 6, "bad face");  // ValueError("bad face"), adi3d_numba_coeff.py:54
-    ADI_REQUIRE(d_mask && d_exposed && nx > 0 && ny > 0 && nz > 0, "adi_exposed_mask: bad argument");
-    const long N = (long)nx * ny * nz;
-    hipLaunchKernelGGL(k_exposed, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), d_mask, nx, ny,
-                       nz, face, d_exposed);
+    ADI_REQUIRE(d_mask && d_exposed, "adi_exposed_mask: null argument");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    hipLaunchKernelGGL(k_exposed, dim3(cell_blocks(L)), dim3(256), 0, as_stream(stream), d_mask, L, face, d_exposed);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }
 
-int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, double dx, double rho, double cp,
-                     const int *h_mode, const double *h_scalar, const double *const *d_h_field,
+int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, double dx, double rho,
+                     double cp, const int *h_mode, const double *h_scalar, const double *const *d_h_field,
                      const int *q_mode, const double *q_scalar, const double *const *d_q_field,
                      double *const *d_coeff, double *const *d_qflux, void *stream)
 {
     ADI_REQUIRE(d_mask && h_mode && h_scalar && q_mode && q_scalar && d_coeff && d_qflux, "adi_build_coeffs: null argument");
-    ADI_REQUIRE(nx > 0 && ny > 0 && nz > 0, "adi_build_coeffs: bad shape");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
     FaceSpec h, q;
     for (int f = 0; f < 6; ++f) {
         h.mode[f] = h_mode[f]; h.scalar[f] = h_scalar[f]; h.field[f] = d_h_field ? d_h_field[f] : nullptr;
@@ -650,87 +933,138 @@ int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, double dx, d
     for (int a = 0; a < 3; ++a) ADI_REQUIRE(d_coeff[a] && d_qflux[a], "adi_build_coeffs: null output");
     // A = dx*dx, V = dx**3 (CPython float_pow -> libm pow), Ccell = rho*cp*V: adi3d_numba_coeff.py:66-68
     const double A = dx * dx, V = pow(dx, 3.0), Ccell = rho * cp * V;
-    const long N = (long)nx * ny * nz;
-    hipLaunchKernelGGL(k_build_coeffs, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), d_mask, nx,
-                       ny, nz, A, Ccell, h, q, d_coeff[0], d_coeff[1], d_coeff[2], d_qflux[0], d_qflux[1], d_qflux[2]);
+    hipLaunchKernelGGL(k_build_coeffs, dim3(cell_blocks(L)), dim3(256), 0, as_stream(stream), d_mask, L, A, Ccell, h,
+                       q, d_coeff[0], d_coeff[1], d_coeff[2], d_qflux[0], d_qflux[1], d_qflux[2]);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }
 
-int adi_build_nbr_flags(const uint8_t *d_mask, int nx, int ny, int nz, uint8_t *d_flags, void *stream)
+int adi_build_nbr_flags(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, uint8_t *d_flags,
+                        void *stream)
 {
-    ADI_REQUIRE(d_mask && d_flags && nx > 0 && ny > 0 && nz > 0, "adi_build_nbr_flags: bad argument");
-    const long N = (long)nx * ny * nz;
-    hipLaunchKernelGGL(k_build_flags, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), d_mask, nx,
-                       ny, nz, d_flags);
+    ADI_REQUIRE(d_mask && d_flags, "adi_build_nbr_flags: null argument");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    hipLaunchKernelGGL(k_build_flags, dim3(cell_blocks(L)), dim3(256), 0, as_stream(stream), d_mask, L, d_flags);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }
 
-int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, double dx, double dt,
-                     double kappa, double theta, double *d_R0, void *stream)
+int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride, double dx,
+                     double dt, double kappa, double theta, double *d_R0, void *stream)
 {
-    ADI_REQUIRE(d_T && d_flags && d_R0 && nx > 0 && ny > 0 && nz > 0, "adi_explicit_rhs: bad argument");
+    ADI_REQUIRE(d_T && d_flags && d_R0, "adi_explicit_rhs: null argument");
     ADI_REQUIRE(d_T != d_R0, "adi_explicit_rhs: output aliases input");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
     const double invdx2 = 1.0 / (dx * dx);
     const double f = dt * kappa * (1.0 - theta);
-    const bool fast = (nz % 2 == 0) && ((((uintptr_t)d_T | (uintptr_t)d_R0) & 15) == 0) && (((uintptr_t)d_flags & 1) == 0);
+    const bool fast = (nz % 2 == 0) && (L.sx % 2 == 0) && ((((uintptr_t)d_T | (uintptr_t)d_R0) & 15) == 0) &&
+                      (((uintptr_t)d_flags & 1) == 0);
     if (fast) {
         const int jslab = (ny + 7) / 8;
         const int nslab = (ny + jslab - 1) / jslab;
         const int ktiles = (nz + 511) / 512;
         const long ntiles = (long)nslab * nx * ((jslab + kExplicitJR - 1) / kExplicitJR) * ktiles;
         hipLaunchKernelGGL(k_explicit_v2, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
-                           nx, ny, nz, invdx2, f, jslab, ktiles, ntiles);
+                           L, invdx2, f, jslab, ktiles, ntiles);
     } else {
-        const long N = (long)nx * ny * nz;
-        hipLaunchKernelGGL(k_explicit, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), d_T,
-                           d_flags, d_R0, nx, ny, nz, invdx2, f);
+        hipLaunchKernelGGL(k_explicit, dim3(cell_blocks(L)), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0, L,
+                           invdx2, f);
     }
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }
 
-int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, size_t *bytes)
+int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, long plane_stride, size_t *bytes)
 {
-    ADI_REQUIRE(axis >= 0 && axis < 3 && bytes && nx > 0 && ny > 0 && nz > 0, "adi_sweep_workspace_bytes: bad argument");
+    ADI_REQUIRE(axis >= 0 && axis < 3 && bytes, "adi_sweep_workspace_bytes: bad argument");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
     const int nn[3] = {nx, ny, nz};
-    *bytes = nn[axis] > kMaxFastLine ? (size_t)2 * nx * ny * nz * sizeof(double) : 0;
+    *bytes = nn[axis] > kMaxFastLine ? (size_t)2 * nx * L.sx * sizeof(double) : 0;
+    return ADI_OK;
+}
+
+static int variant_flags(int variant, bool *has_dir, bool *has_q)
+{
+    if (variant < 0 || variant > 3) return set_err(ADI_ERR_ARG, "bad sweep variant %d", variant);
+    *has_dir = (variant == ADI_SWEEP_GENERAL || variant == ADI_SWEEP_NO_Q);
+    *has_q = (variant == ADI_SWEEP_GENERAL || variant == ADI_SWEEP_NO_DIR);
     return ADI_OK;
 }
 
 int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
               const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
-              double theta, double gam, double dt, double Tinf, double *d_out, void *d_work, size_t work_bytes,
-              void *stream)
+              long plane_stride, double theta, double gam, double dt, double Tinf, double *d_out,
+              const double *d_xlo, const double *d_xhi, void *d_work, size_t work_bytes, void *stream)
 {
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep: bad axis %d", axis);
-    ADI_REQUIRE(variant >= 0 && variant <= 3, "adi_sweep: bad variant %d", variant);
-    ADI_REQUIRE(d_in && d_flags && d_coeff && d_out && nx > 0 && ny > 0 && nz > 0, "adi_sweep: bad argument");
+    bool has_dir, has_q;
+    if (int rc = variant_flags(variant, &has_dir, &has_q)) return rc;
+    ADI_REQUIRE(d_in && d_flags && d_coeff && d_out, "adi_sweep: null argument");
     ADI_REQUIRE(d_in != d_out, "adi_sweep: output aliases input");
-    const bool has_dir = (variant == ADI_SWEEP_GENERAL || variant == ADI_SWEEP_NO_Q);
-    const bool has_q = (variant == ADI_SWEEP_GENERAL || variant == ADI_SWEEP_NO_DIR);
     ADI_REQUIRE(!has_dir || (d_dir_mask && d_dir_val), "adi_sweep: variant needs Dirichlet arrays");
     ADI_REQUIRE(!has_q || d_qflux, "adi_sweep: variant needs the flux array");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
     SweepScal s;
     s.tg = theta * gam;
     s.dt = dt;
     s.Tinf = Tinf;
     hipStream_t st = as_stream(stream);
     int rc;
-    if (has_dir && has_q) rc = sweep_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, s, d_out, d_work, work_bytes, st);
-    else if (has_q) rc = sweep_dispatch<false, true>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, d_qflux, nx, ny, nz, s, d_out, d_work, work_bytes, st);
-    else if (has_dir) rc = sweep_dispatch<true, false>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, nullptr, nx, ny, nz, s, d_out, d_work, work_bytes, st);
-    else rc = sweep_dispatch<false, false>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, nullptr, nx, ny, nz, s, d_out, d_work, work_bytes, st);
+    if (has_dir && has_q) rc = sweep_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st);
+    else if (has_q) rc = sweep_dispatch<false, true>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, d_qflux, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st);
+    else if (has_dir) rc = sweep_dispatch<true, false>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, nullptr, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st);
+    else rc = sweep_dispatch<false, false>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, nullptr, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st);
     if (rc != ADI_OK) return rc;
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
+                       const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny,
+                       int nz, long plane_stride, double theta, double gam, double dt, double Tinf, double *d_cond,
+                       void *stream)
+{
+    ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep_condense: bad axis %d", axis);
+    bool has_dir, has_q;
+    if (int rc = variant_flags(variant, &has_dir, &has_q)) return rc;
+    ADI_REQUIRE(d_in && d_flags && d_coeff && d_cond, "adi_sweep_condense: null argument");
+    ADI_REQUIRE(!has_dir || (d_dir_mask && d_dir_val), "adi_sweep_condense: variant needs Dirichlet arrays");
+    ADI_REQUIRE(!has_q || d_qflux, "adi_sweep_condense: variant needs the flux array");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    SweepScal s;
+    s.tg = theta * gam;
+    s.dt = dt;
+    s.Tinf = Tinf;
+    hipStream_t st = as_stream(stream);
+    if (has_dir && has_q) condense_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, L, s, d_cond, st);
+    else if (has_q) condense_dispatch<false, true>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, d_qflux, L, s, d_cond, st);
+    else if (has_dir) condense_dispatch<true, false>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, nullptr, L, s, d_cond, st);
+    else condense_dispatch<false, false>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, nullptr, L, s, d_cond, st);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+int adi_interface_solve(const double *d_cond_all, int nranks, int rank, long nlines, double *d_xlo, double *d_xhi,
+                        void *stream)
+{
+    ADI_REQUIRE(d_cond_all && d_xlo && d_xhi && nranks >= 1 && rank >= 0 && rank < nranks && nlines > 0,
+                "adi_interface_solve: bad argument");
+    hipLaunchKernelGGL(k_interface, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, as_stream(stream), d_cond_all,
+                       nranks, rank, nlines, d_xlo, d_xhi);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }
 
 int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b, const uint8_t *d_flags,
              const double *const *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
-             const double *const *d_qflux, int variant, int nx, int ny, int nz, double dx, double rho, double cp,
-             double k, double dt, double theta, double Tinf, void *d_work, size_t work_bytes, void *stream)
+             const double *const *d_qflux, int variant, int nx, int ny, int nz, long plane_stride, double dx,
+             double rho, double cp, double k, double dt, double theta, double Tinf, void *d_work, size_t work_bytes,
+             void *stream)
 {
     ADI_REQUIRE(d_T_in && d_T_out && d_tmp_a && d_tmp_b && d_coeff, "adi_step: null argument");
     ADI_REQUIRE(d_tmp_a != d_tmp_b && d_tmp_a != d_T_in && d_tmp_b != d_T_in && d_T_out != d_tmp_a && d_T_out != d_T_in,
@@ -739,13 +1073,13 @@ int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_t
     const double kappa = k / (rho * cp);
     const double gam = kappa * dt / (dx * dx);
     const double *q0 = d_qflux ? d_qflux[0] : nullptr, *q1 = d_qflux ? d_qflux[1] : nullptr, *q2 = d_qflux ? d_qflux[2] : nullptr;
-    int rc = adi_explicit_rhs(d_T_in, d_flags, nx, ny, nz, dx, dt, kappa, theta, d_tmp_a, stream);
+    int rc = adi_explicit_rhs(d_T_in, d_flags, nx, ny, nz, plane_stride, dx, dt, kappa, theta, d_tmp_a, stream);
     if (rc) return rc;
-    rc = adi_sweep(0, variant, d_tmp_a, d_flags, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, theta, gam, dt, Tinf, d_tmp_b, d_work, work_bytes, stream);
+    rc = adi_sweep(0, variant, d_tmp_a, d_flags, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, plane_stride, theta, gam, dt, Tinf, d_tmp_b, nullptr, nullptr, d_work, work_bytes, stream);
     if (rc) return rc;
-    rc = adi_sweep(1, variant, d_tmp_b, d_flags, d_coeff[1], d_dir_mask, d_dir_val, q1, nx, ny, nz, theta, gam, dt, Tinf, d_tmp_a, d_work, work_bytes, stream);
+    rc = adi_sweep(1, variant, d_tmp_b, d_flags, d_coeff[1], d_dir_mask, d_dir_val, q1, nx, ny, nz, plane_stride, theta, gam, dt, Tinf, d_tmp_a, nullptr, nullptr, d_work, work_bytes, stream);
     if (rc) return rc;
-    return adi_sweep(2, variant, d_tmp_a, d_flags, d_coeff[2], d_dir_mask, d_dir_val, q2, nx, ny, nz, theta, gam, dt, Tinf, d_T_out, d_work, work_bytes, stream);
+    return adi_sweep(2, variant, d_tmp_a, d_flags, d_coeff[2], d_dir_mask, d_dir_val, q2, nx, ny, nz, plane_stride, theta, gam, dt, Tinf, d_T_out, nullptr, nullptr, d_work, work_bytes, stream);
 }
 
 int adi_masked_fill(double *d_T, const uint8_t *d_sel, size_t n, double value, void *stream)

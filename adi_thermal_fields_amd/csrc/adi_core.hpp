@@ -129,6 +129,78 @@ __device__ __forceinline__ void back_solve(const double (&a)[M], const double (&
     x[M - 1] = xS;
 }
 
+
+// ---- whole-block condensation and merging (distributed / two-level solves) ----------------------
+// condense_full: like condense(), but ALL M rows form the block (no separator): first/last unknown of
+// the block as affine functions of the value left of row 0 (xl) and right of row M-1 (xr):
+//   x_first = gF - aF * xl - cF * xr        x_last = gL - aL * xl - cL * xr
+template <int M>
+__device__ __forceinline__ void condense_full(const double (&a)[M], const double (&b)[M], const double (&c)[M],
+                                              const double (&d)[M], Cond &k)
+{
+    double y = d[0], e = 1.0;
+    double ip = frcp(b[0]);
+#pragma unroll
+    for (int r = 1; r < M; ++r) {
+        const double w = a[r] * ip;
+        ip = frcp(__builtin_fma(-w, c[r - 1], b[r]));
+        y = __builtin_fma(-w, y, d[r]);
+        e = -w * e;
+    }
+    k.gL = y * ip;
+    k.aL = a[0] * (e * ip);
+    k.cL = c[M - 1] * ip;
+    double jp = frcp(b[M - 1]);
+    double z = d[M - 1], f = 1.0;
+#pragma unroll
+    for (int r = M - 2; r >= 0; --r) {
+        const double w = c[r] * jp;
+        jp = frcp(__builtin_fma(-w, a[r + 1], b[r]));
+        z = __builtin_fma(-w, z, d[r]);
+        f = -w * f;
+    }
+    k.gF = z * jp;
+    k.aF = a[0] * jp;
+    k.cF = c[M - 1] * (f * jp);
+}
+
+// Condensation of the concatenation [A | B] of two adjacent blocks (A's last row couples to B's first).
+__device__ __forceinline__ Cond merge_cond(const Cond &A, const Cond &B)
+{
+    const double idet = frcp(__builtin_fma(-A.cL, B.aF, 1.0));
+    const double v0 = __builtin_fma(-B.aF, A.gL, B.gF) * idet;   // x_F^B at xl = xr = 0
+    const double u0 = __builtin_fma(-A.cL, B.gF, A.gL) * idet;   // x_L^A at xl = xr = 0
+    Cond R;
+    R.gF = __builtin_fma(-A.cF, v0, A.gF);
+    R.aF = __builtin_fma(A.cF * B.aF, A.aL * idet, A.aF);
+    R.cF = -(A.cF * B.cF) * idet;
+    R.gL = __builtin_fma(-B.aL, u0, B.gL);
+    R.aL = -(B.aL * A.aL) * idet;
+    R.cL = __builtin_fma(B.aL * A.cL, B.cF * idet, B.cL);
+    return R;
+}
+
+__device__ __forceinline__ Cond shfl_down_cond(const Cond &k, int delta, int width)
+{
+    Cond r;
+    r.gF = __shfl_down(k.gF, delta, width); r.aF = __shfl_down(k.aF, delta, width);
+    r.cF = __shfl_down(k.cF, delta, width); r.gL = __shfl_down(k.gL, delta, width);
+    r.aL = __shfl_down(k.aL, delta, width); r.cL = __shfl_down(k.cL, delta, width);
+    return r;
+}
+
+// Ordered tree reduction over the Lp lanes of a line: lane 0 ends up with the condensation of all blocks
+// li = 0..nblk-1 (lanes >= nblk hold nothing and are skipped).
+__device__ __forceinline__ Cond reduce_cond(Cond k, int li, int Lp, int nblk)
+{
+    for (int dl = 1; dl < Lp; dl <<= 1) {
+        const Cond o = shfl_down_cond(k, dl, Lp);
+        // lane li (a multiple of 2*dl) holds blocks [li, li+dl), its partner holds [li+dl, li+2dl)
+        if (((li & (2 * dl - 1)) == 0) && (li + dl) < nblk) k = merge_cond(k, o);
+    }
+    return k;
+}
+
 // Bijective XCD-aware block remap: blocks b, b+8, b+16, ... are observed to share an XCD (and its
 // L2); give each XCD a contiguous chunk of the tile range so neighbouring tiles hit the same L2.
 // Placement only changes speed, never results.

@@ -30,7 +30,8 @@ using namespace adi;
 struct adi_ctx {
     int nx, ny, nz, device;
     double dx;
-    size_t N;
+    long sx;             // padded plane stride (elements)
+    size_t N;            // allocated elements per field = nx * sx
     uint8_t *mask, *flags, *dir_mask;
     double *T[2];        // ping-pong state
     double *tmp[2];      // stage scratch
@@ -57,6 +58,16 @@ static void ctx_free(adi_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+// dense host array <-> padded-plane device array
+static hipError_t copy_planes(adi_ctx *c, void *dst, const void *src, size_t elem, bool to_device)
+{
+    const size_t row = (size_t)c->ny * c->nz * elem;
+    const size_t dpitch = to_device ? (size_t)c->sx * elem : row;
+    const size_t spitch = to_device ? row : (size_t)c->sx * elem;
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, row, c->nx, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
+                            c->stream);
 }
 
 extern "C" {
@@ -94,7 +105,8 @@ int adi_ctx_create(int nx, int ny, int nz, double dx, int device, adi_ctx **out)
     if (!c) return set_err(ADI_ERR_HIP, "adi_ctx_create: out of host memory");
     memset(c, 0, sizeof(*c));
     c->nx = nx; c->ny = ny; c->nz = nz; c->dx = dx; c->device = device;
-    c->N = (size_t)nx * ny * nz;
+    c->sx = adi_recommended_plane_stride(ny, nz);
+    c->N = (size_t)nx * c->sx;
     const size_t fb = c->N * sizeof(double);
 #define CTX_ALLOC(ptr, bytes)                                                          \
     do {                                                                               \
@@ -113,7 +125,7 @@ int adi_ctx_create(int nx, int ny, int nz, double dx, int device, adi_ctx **out)
     size_t wb = 0;
     for (int a = 0; a < 3; ++a) {
         size_t b = 0;
-        adi_sweep_workspace_bytes(a, nx, ny, nz, &b);
+        adi_sweep_workspace_bytes(a, nx, ny, nz, c->sx, &b);
         if (b > wb) wb = b;
     }
     if (wb) CTX_ALLOC(c->work, wb);
@@ -138,8 +150,9 @@ int adi_ctx_set_mask(adi_ctx *c, const uint8_t *h_mask)
 {
     ADI_REQUIRE(c && h_mask, "adi_ctx_set_mask: null argument");
     ADI_HIP_TRY(hipSetDevice(c->device));
-    ADI_HIP_TRY(hipMemcpyAsync(c->mask, h_mask, c->N, hipMemcpyHostToDevice, c->stream));
-    int rc = adi_build_nbr_flags(c->mask, c->nx, c->ny, c->nz, c->flags, c->stream);
+    ADI_HIP_TRY(hipMemsetAsync(c->mask, 0, c->N, c->stream));
+    ADI_HIP_TRY(copy_planes(c, c->mask, h_mask, 1, true));
+    int rc = adi_build_nbr_flags(c->mask, c->nx, c->ny, c->nz, c->sx, c->flags, c->stream);
     if (rc != ADI_OK) return rc;
     ADI_HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_mask = true;
@@ -164,7 +177,7 @@ int adi_ctx_build_coeffs(adi_ctx *c, double rho, double cp, const int *h_mode, c
         double *d = nullptr;
         if (hipMalloc((void **)&d, fb) != hipSuccess) return nullptr;
         staged[ns++] = d;
-        if (hipMemcpyAsync(d, host, fb, hipMemcpyHostToDevice, c->stream) != hipSuccess) return nullptr;
+        if (copy_planes(c, d, host, sizeof(double), true) != hipSuccess) return nullptr;
         return d;
     };
     for (int f = 0; f < 6 && rc == ADI_OK; ++f) {
@@ -178,19 +191,21 @@ int adi_ctx_build_coeffs(adi_ctx *c, double rho, double cp, const int *h_mode, c
         }
     }
     if (rc == ADI_OK)
-        rc = adi_build_coeffs(c->mask, c->nx, c->ny, c->nz, c->dx, rho, cp, h_mode, h_scalar, dh, q_mode, q_scalar, dq,
+        rc = adi_build_coeffs(c->mask, c->nx, c->ny, c->nz, c->sx, c->dx, rho, cp, h_mode, h_scalar, dh, q_mode, q_scalar, dq,
                               c->coeff, c->qflux, c->stream);
     bool has_dir = false, has_q = false;
     if (rc == ADI_OK) {
         for (int f = 0; f < 6; ++f) has_q = has_q || (q_mode[f] != ADI_FACE_NONE);
         if (h_dir_mask) {
-            for (size_t p = 0; p < c->N && !has_dir; ++p) has_dir = h_dir_mask[p] != 0;
+            const size_t nd = (size_t)c->nx * c->ny * c->nz;
+            for (size_t p = 0; p < nd && !has_dir; ++p) has_dir = h_dir_mask[p] != 0;
         }
         if (has_dir) {
-            if (hipMemcpyAsync(c->dir_mask, h_dir_mask, c->N, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            if (hipMemsetAsync(c->dir_mask, 0, c->N, c->stream) != hipSuccess ||
+                copy_planes(c, c->dir_mask, h_dir_mask, 1, true) != hipSuccess)
                 rc = set_err(ADI_ERR_HIP, "adi_ctx_build_coeffs: dir_mask upload failed");
             if (rc == ADI_OK) {
-                hipError_t e = h_dir_val ? hipMemcpyAsync(c->dir_val, h_dir_val, fb, hipMemcpyHostToDevice, c->stream)
+                hipError_t e = h_dir_val ? copy_planes(c, c->dir_val, h_dir_val, sizeof(double), true)
                                          : hipMemsetAsync(c->dir_val, 0, fb, c->stream);  // dir_value None -> 0 (:75-76)
                 if (e != hipSuccess) rc = set_err(ADI_ERR_HIP, "adi_ctx_build_coeffs: dir_val upload failed");
             }
@@ -209,7 +224,7 @@ int adi_ctx_upload_T(adi_ctx *c, const double *h_T)
 {
     ADI_REQUIRE(c && h_T, "adi_ctx_upload_T: null argument");
     ADI_HIP_TRY(hipSetDevice(c->device));
-    ADI_HIP_TRY(hipMemcpyAsync(c->T[c->cur], h_T, c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ADI_HIP_TRY(copy_planes(c, c->T[c->cur], h_T, sizeof(double), true));
     ADI_HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_T = true;
     return ADI_OK;
@@ -220,7 +235,7 @@ int adi_ctx_download_T(adi_ctx *c, double *h_T)
     ADI_REQUIRE(c && h_T, "adi_ctx_download_T: null argument");
     if (!c->have_T) return set_err(ADI_ERR_STATE, "adi_ctx_download_T: no field uploaded");
     ADI_HIP_TRY(hipSetDevice(c->device));
-    ADI_HIP_TRY(hipMemcpyAsync(h_T, c->T[c->cur], c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    ADI_HIP_TRY(copy_planes(c, h_T, c->T[c->cur], sizeof(double), false));
     ADI_HIP_TRY(hipStreamSynchronize(c->stream));
     return ADI_OK;
 }
@@ -230,8 +245,8 @@ int adi_ctx_download_pack(adi_ctx *c, int axis, double *h_coeff, double *h_qflux
     ADI_REQUIRE(c && axis >= 0 && axis < 3, "adi_ctx_download_pack: bad argument");
     if (!c->have_packs) return set_err(ADI_ERR_STATE, "adi_ctx_download_pack: packs not built");
     ADI_HIP_TRY(hipSetDevice(c->device));
-    if (h_coeff) ADI_HIP_TRY(hipMemcpyAsync(h_coeff, c->coeff[axis], c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (h_qflux) ADI_HIP_TRY(hipMemcpyAsync(h_qflux, c->qflux[axis], c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (h_coeff) ADI_HIP_TRY(copy_planes(c, h_coeff, c->coeff[axis], sizeof(double), false));
+    if (h_qflux) ADI_HIP_TRY(copy_planes(c, h_qflux, c->qflux[axis], sizeof(double), false));
     ADI_HIP_TRY(hipStreamSynchronize(c->stream));
     return ADI_OK;
 }
@@ -246,7 +261,7 @@ int adi_ctx_step(adi_ctx *c, double rho, double cp, double k, double dt, double 
     for (int s = 0; s < nsteps; ++s) {
         const int nxt = c->cur ^ 1;
         int rc = adi_step(c->T[c->cur], c->T[nxt], c->tmp[0], c->tmp[1], c->flags, c->coeff, c->dir_mask, c->dir_val,
-                          c->qflux, c->variant, c->nx, c->ny, c->nz, c->dx, rho, cp, k, dt, theta, Tinf, c->work,
+                          c->qflux, c->variant, c->nx, c->ny, c->nz, c->sx, c->dx, rho, cp, k, dt, theta, Tinf, c->work,
                           c->work_bytes, c->stream);
         if (rc != ADI_OK) return rc;
         c->cur = nxt;

@@ -27,6 +27,7 @@
 
 struct adi_cyl_plan {
     int nr, nphi, nz, device;
+    long sx;  // plane (one radius) stride in elements
     double rho, cp, dt;
     // r sweep
     double *d_ar, *d_br, *d_cr;  // [nr]
@@ -170,7 +171,7 @@ template <int M, bool VEC>
 __global__ __launch_bounds__(256) void k_cyl_contig(const double *__restrict__ in, double *__restrict__ out,
                                                    long nlines, int n, int Lp, CylZ z,
                                                    const uint8_t *__restrict__ active_mask, double T_void,
-                                                   double T_inner, long lines_per_r0)
+                                                   double T_inner, long lines_per_r0, long sx)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lw = 64 / Lp;
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(256) void k_cyl_contig(const double *__restrict__ i
     const long line = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * lw + (lane / Lp);
     const bool active = line < nlines;
     const int r0 = li * M;
-    const long base = line * (long)n + r0;
+    const long pi = line / lines_per_r0;   // radius index; lines_per_r0 = nphi
+    const long base = pi * sx + (line - pi * lines_per_r0) * (long)n + r0;
 
     double a[M], b[M], c[M], d[M];
     if (VEC) {
@@ -260,7 +262,7 @@ static void launch_cyl_strided(const double *in, double *out, int n, long stride
                                const uint8_t *act, double T_void, hipStream_t st)
 {
     const int Lp = next_pow2((n + M - 1) / M);
-    int lines = (M <= 8) ? 16 : 8;
+    int lines = 8;
     while (lines * Lp < 256) lines <<= 1;
     const int tiles_inner = (n_inner + lines - 1) / lines;
     const long ntiles = (long)tiles_inner * n_outer;
@@ -285,17 +287,17 @@ static void dispatch_cyl_strided(const double *in, double *out, int n, long stri
 
 template <int M>
 static void launch_cyl_contig(const double *in, double *out, long nlines, int n, const CylZ &z, const uint8_t *act,
-                              double T_void, double T_inner, long lines_per_r0, hipStream_t st)
+                              double T_void, double T_inner, long lines_per_r0, long sx, hipStream_t st)
 {
     const int Lp = next_pow2((n + M - 1) / M);
     const int lw = 64 / Lp;
     const long waves = (nlines + lw - 1) / lw;
     const unsigned grid = (unsigned)((waves + 3) / 4);
-    const bool vec = ((((uintptr_t)in | (uintptr_t)out) & 15) == 0) && (n % M == 0);
+    const bool vec = ((((uintptr_t)in | (uintptr_t)out) & 15) == 0) && (n % M == 0) && (sx % 2 == 0);
     if (vec)
-        hipLaunchKernelGGL((k_cyl_contig<M, true>), dim3(grid), dim3(256), 0, st, in, out, nlines, n, Lp, z, act, T_void, T_inner, lines_per_r0);
+        hipLaunchKernelGGL((k_cyl_contig<M, true>), dim3(grid), dim3(256), 0, st, in, out, nlines, n, Lp, z, act, T_void, T_inner, lines_per_r0, sx);
     else
-        hipLaunchKernelGGL((k_cyl_contig<M, false>), dim3(grid), dim3(256), 0, st, in, out, nlines, n, Lp, z, act, T_void, T_inner, lines_per_r0);
+        hipLaunchKernelGGL((k_cyl_contig<M, false>), dim3(grid), dim3(256), 0, st, in, out, nlines, n, Lp, z, act, T_void, T_inner, lines_per_r0, sx);
 }
 
 }  // namespace adi
@@ -314,7 +316,8 @@ static void plan_free(adi_cyl_plan *p)
 
 extern "C" {
 
-int adi_cyl_plan_create(int nr, int nphi, int nz, double dr, double dphi, double dz, double rho, double cp, double k,
+int adi_cyl_plan_create(int nr, int nphi, int nz, long plane_stride, double dr, double dphi, double dz, double rho,
+                        double cp, double k,
                         double dt, double robin_h, double robin_Tinf, int kind_bot, int kind_top, double h_bot,
                         double h_top, double Tinf_bot, double Tinf_top, double T_bot, double T_top,
                         adi_cyl_plan **out)
@@ -330,6 +333,8 @@ int adi_cyl_plan_create(int nr, int nphi, int nz, double dr, double dphi, double
     memset(p, 0, sizeof(*p));
     ADI_HIP_TRY(hipGetDevice(&p->device));
     p->nr = nr; p->nphi = nphi; p->nz = nz; p->rho = rho; p->cp = cp; p->dt = dt;
+    p->sx = plane_stride ? plane_stride : (long)nphi * nz;
+    if (p->sx < (long)nphi * nz) { delete p; return set_err(ADI_ERR_ARG, "adi_cyl_plan_create: plane_stride < nphi*nz"); }
     const double alpha = k / (rho * cp);  // Material.alpha, :48-50
     const double theta = 1.0;             // BE branch calls the builders with theta = 1.0 (:341, :348)
 
@@ -437,12 +442,12 @@ int adi_cyl_step(const adi_cyl_plan *pl, const double *d_T_in, double *d_T_out, 
     ADI_REQUIRE(plane <= 0x7fffffffL, "adi_cyl_step: (nphi, nz) plane too large");
     // r sweep: T_in -> tmp_a (source and void pre-clamp fused)
     const double s_scale = pl->dt * (1.0 / (pl->rho * pl->cp));
-    dispatch_cyl_strided<0>(d_T_in, d_tmp_a, nr, plane, (int)plane, 1, 0, pl, d_S, s_scale, d_active, T_void, st);
+    dispatch_cyl_strided<0>(d_T_in, d_tmp_a, nr, pl->sx, (int)plane, 1, 0, pl, d_S, s_scale, d_active, T_void, st);
     ADI_CHECK_LAUNCH();
     // phi sweep: tmp_a -> tmp_b   (nphi == 1: the reference returns a copy, :303-304)
     const double *zin = d_tmp_a;
     if (nphi > 1) {
-        dispatch_cyl_strided<1>(d_tmp_a, d_tmp_b, nphi, nz, nz, nr, plane, pl, nullptr, 0.0, nullptr, 0.0, st);
+        dispatch_cyl_strided<1>(d_tmp_a, d_tmp_b, nphi, nz, nz, nr, pl->sx, pl, nullptr, 0.0, nullptr, 0.0, st);
         ADI_CHECK_LAUNCH();
         zin = d_tmp_b;
     }
@@ -452,10 +457,10 @@ int adi_cyl_step(const adi_cyl_plan *pl, const double *d_T_in, double *d_T_out, 
     z.addN = pl->zaddN; z.T0 = pl->zT0; z.TN = pl->zTN; z.dir0 = pl->zdir0; z.dirN = pl->zdirN;
     const long nlines = (long)nr * nphi;
     switch (contig_rows(nz)) {
-        case 2: launch_cyl_contig<2>(zin, d_T_out, nlines, nz, z, d_active, T_void, T_inner, nphi, st); break;
-        case 4: launch_cyl_contig<4>(zin, d_T_out, nlines, nz, z, d_active, T_void, T_inner, nphi, st); break;
-        case 8: launch_cyl_contig<8>(zin, d_T_out, nlines, nz, z, d_active, T_void, T_inner, nphi, st); break;
-        default: launch_cyl_contig<16>(zin, d_T_out, nlines, nz, z, d_active, T_void, T_inner, nphi, st); break;
+        case 2: launch_cyl_contig<2>(zin, d_T_out, nlines, nz, z, d_active, T_void, T_inner, nphi, pl->sx, st); break;
+        case 4: launch_cyl_contig<4>(zin, d_T_out, nlines, nz, z, d_active, T_void, T_inner, nphi, pl->sx, st); break;
+        case 8: launch_cyl_contig<8>(zin, d_T_out, nlines, nz, z, d_active, T_void, T_inner, nphi, pl->sx, st); break;
+        default: launch_cyl_contig<16>(zin, d_T_out, nlines, nz, z, d_active, T_void, T_inner, nphi, pl->sx, st); break;
     }
     ADI_CHECK_LAUNCH();
     return ADI_OK;

@@ -155,10 +155,11 @@ def main():
         Tin = T
         ms = []
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        out = torch.empty_like(Tin.t)
+        out = grid.layout.empty()
+        tin = grid.layout.to_layout(Tin, torch.float64)
         for it in range(13):
             e0.record()
-            stepper.sweep_into(2, Tin.t, out, variant=_lib.SWEEP_GENERAL)
+            stepper.sweep_into(2, tin, out, variant=_lib.SWEEP_GENERAL)
             e1.record(); e1.synchronize()
             if it >= 3:
                 ms.append(e0.elapsed_time(e1))

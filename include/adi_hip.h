@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 1
+#define ADI_ABI_VERSION 2
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -60,10 +60,17 @@ int         adi_device_info(int device, char *name, int *cu_count, size_t *hbm_b
 
 /* ------------------------------------------------------------------------------------------------
  * Stateless device entry points (caller-owned device memory).
+ *
+ * Device layout of every field and mask: element (i, j, k) at i*plane_stride + j*nz + k, with
+ * plane_stride >= ny*nz in ELEMENTS (0 means dense, ny*nz).  A padded plane stride keeps the rows of an
+ * axis-0 line off the same HBM channels; adi_recommended_plane_stride() returns the pitch this library
+ * wants for a given (ny, nz).  Per-line arrays (d_xlo, d_xhi, d_cond) are dense.
  * ---------------------------------------------------------------------------------------------- */
+long adi_recommended_plane_stride(int ny, int nz);
 
 /* exposed_mask(mask, face): adi3d_numba_coeff.py:38-55 / adi3d_gpu_coeff.py:31-48 */
-int adi_exposed_mask(const uint8_t *d_mask, int nx, int ny, int nz, int face, uint8_t *d_exposed, void *stream);
+int adi_exposed_mask(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, int face,
+                     uint8_t *d_exposed, void *stream);
 
 /*
  * precompute_coeff_packs_unified: adi3d_numba_coeff.py:57-118 / adi3d_gpu_coeff.py:50-110.
@@ -73,7 +80,8 @@ int adi_exposed_mask(const uint8_t *d_mask, int nx, int ny, int nz, int face, ui
  * h_mode/q_mode[6]: ADI_FACE_*; h_scalar/q_scalar[6]; h_field/q_field[6]: device pointers or NULL.
  * d_coeff[3], d_qflux[3]: device output fields (fully overwritten).
  */
-int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, double dx, double rho, double cp,
+int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, double dx,
+                     double rho, double cp,
                      const int *h_mode, const double *h_scalar, const double *const *d_h_field,
                      const int *q_mode, const double *q_scalar, const double *const *d_q_field,
                      double *const *d_coeff, double *const *d_qflux, void *stream);
@@ -85,24 +93,43 @@ int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, double dx, d
  * Rebuild whenever the mask changes (same moment the packs are rebuilt, waam_from_stl_v7_mm.py:494-495, :534).
  * For a slab of a larger grid, build the flags on the slab plus its two halo planes and pass the interior.
  */
-int adi_build_nbr_flags(const uint8_t *d_mask, int nx, int ny, int nz, uint8_t *d_flags, void *stream);
+int adi_build_nbr_flags(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride,
+                        uint8_t *d_flags, void *stream);
 
 /* lap1D_x/y/z + R0 = Tn + dt*kappa*(1-theta)*(Lx+Ly+Lz): adi3d_numba_coeff.py:240-288, :298 */
-int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, double dx,
-                     double dt, double kappa, double theta, double *d_R0, void *stream);
+int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride,
+                     double dx, double dt, double kappa, double theta, double *d_R0, void *stream);
 
 /*
  * sweep_axis0/1/2: adi3d_numba_coeff.py:133-237 (full-length identity-row form of
  * adi3d_gpu_coeff.py:154-191).  One independent tridiagonal system per grid line along `axis`.
- * variant: ADI_SWEEP_*; arrays a variant does not read may be NULL.
- * d_out must not alias d_in.  d_work/work_bytes: scratch for lines longer than the in-register
- * limit (adi_sweep_workspace_bytes); may be NULL/0 otherwise.
+ * variant: ADI_SWEEP_*; arrays a variant does not read may be NULL.  d_out must not alias d_in.
+ * d_xlo / d_xhi (optional, dense, one value per line): value of the unknown just before the first / after
+ * the last local row when the line continues on a neighbouring GPU (see adi_interface_solve); the coupling
+ * itself is read from the halo bits of d_flags.  NULL for a stand-alone grid.
+ * d_work/work_bytes: scratch for lines longer than the in-register limit (adi_sweep_workspace_bytes).
  */
 int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
               const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux,
-              int nx, int ny, int nz, double theta, double gam, double dt, double Tinf,
-              double *d_out, void *d_work, size_t work_bytes, void *stream);
-int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, size_t *bytes);
+              int nx, int ny, int nz, long plane_stride, double theta, double gam, double dt, double Tinf,
+              double *d_out, const double *d_xlo, const double *d_xhi,
+              void *d_work, size_t work_bytes, void *stream);
+int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, long plane_stride, size_t *bytes);
+
+/*
+ * Slab decomposition of a sweep (no counterpart in the reference, which is single-process): pass A.
+ * For every line, the local rows are condensed to six numbers (d_cond: [6][nlines], dense) such that
+ *   x_first = c0 - c1*xl - c2*xr,   x_last = c3 - c4*xl - c5*xr
+ * with xl / xr the unknowns adjacent to the slab on the neighbouring GPUs.  Same inputs as adi_sweep.
+ */
+int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t *d_flags,
+                       const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
+                       const double *d_qflux, int nx, int ny, int nz, long plane_stride,
+                       double theta, double gam, double dt, double Tinf, double *d_cond, void *stream);
+/* d_cond_all: [nranks][6][nlines], the all-gathered pass-A output ordered by slab.  Solves the reduced
+ * interface system of every line and writes this rank's boundary values for pass B (adi_sweep). */
+int adi_interface_solve(const double *d_cond_all, int nranks, int rank, long nlines,
+                        double *d_xlo, double *d_xhi, void *stream);
 
 /*
  * adi_step_numba_coeff / adi_step_gpu_coeff: adi3d_numba_coeff.py:290-302, adi3d_gpu_coeff.py:213-230.
@@ -112,17 +139,18 @@ int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, size_t *bytes);
 int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b,
              const uint8_t *d_flags, const double *const *d_coeff, const uint8_t *d_dir_mask,
              const double *d_dir_val, const double *const *d_qflux, int variant,
-             int nx, int ny, int nz, double dx, double rho, double cp, double k,
+             int nx, int ny, int nz, long plane_stride, double dx, double rho, double cp, double k,
              double dt, double theta, double Tinf, void *d_work, size_t work_bytes, void *stream);
 
-/* T[sel != 0] = value   (layer birth: waam_from_stl_v7_mm.py:487-495 `T[newborn] = Ts`) */
+/* T[sel != 0] = value   (layer birth: waam_from_stl_v7_mm.py:487-495 `T[newborn] = Ts`); flat over n elements */
 int adi_masked_fill(double *d_T, const uint8_t *d_sel, size_t n, double value, void *stream);
 /* dst = a | b  (birth bookkeeping: mask_act |= newborn) */
 int adi_mask_or(uint8_t *d_dst, const uint8_t *d_a, const uint8_t *d_b, size_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Cylindrical (r, phi, z) backward-Euler step: adi3d_cyl_phi_v3.py:332-350 (scheme="be").
- * Field layout C-order (nr, nphi, nz).  d_S may be NULL (no source).  d_tmp_a/d_tmp_b: scratch fields.
+ * Field layout (nr, nphi, nz) with the same padded-plane convention (plane = one radius).
+ * d_S may be NULL (no source).  d_tmp_a/d_tmp_b: scratch fields.
  * d_active (optional, may be NULL): adi_step_masked of quick_spiral_deposition_gif_v5.py:31-70 --
  * void cells are clamped to T_void before and after the step, inactive axis-row cells to T_inner.
  * ---------------------------------------------------------------------------------------------- */
@@ -131,7 +159,7 @@ typedef struct adi_cyl_plan adi_cyl_plan;
  * the r coefficients of build_coeff_r (:155-202), the per-radius phi factors of phi_solve_spectral
  * (:302-329) and the z closures of build_coeff_z (:255-298).  Created on the current device.
  * ADI_ERR_ARG ("unknown zbc.kind_bot/top") mirrors the reference's ValueError (:283, :296). */
-int adi_cyl_plan_create(int nr, int nphi, int nz, double dr, double dphi, double dz,
+int adi_cyl_plan_create(int nr, int nphi, int nz, long plane_stride, double dr, double dphi, double dz,
                         double rho, double cp, double k, double dt,
                         double robin_h, double robin_Tinf,
                         int kind_bot, int kind_top, double h_bot, double h_top,
