@@ -38,7 +38,7 @@ def main():
     torch.cuda.synchronize()
     print('pack build s', time.time() - t0)
     g = torch.Generator(device=dev); g.manual_seed(0)
-    T = adi.DeviceField(torch.rand(shape, dtype=torch.float64, device=dev, generator=g) * 980.0 + 20.0)
+    T = adi.DeviceField(grid.layout.to_layout(torch.rand(shape, dtype=torch.float64, device=dev, generator=g) * 980.0 + 20.0, torch.float64))
     res = {}
     ms, mn = timeit(lambda: adi.adi_explicit_rhs(T, grid, mat, prm))
     res['explicit'] = (ms, mn, 17 * N / mn / 1e6)
