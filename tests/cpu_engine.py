@@ -1,0 +1,147 @@
+"""Reference engine for the slab decomposition (tests only): NumPy/oracle restatements of the five engine
+calls of adi_thermal_fields_amd.dist_slab, on CPU tensors, so the exchange logic and the algebra of the
+reduced interface system can be run on gloo ranks without a GPU.  The interface solve here assembles the
+dense (2R x 2R) system per line instead of merging, as an independent check of the product's method."""
+import numpy as np
+import torch
+
+from oracle import adi_oracle as orc
+
+
+class CpuLayout:
+    def __init__(self, nx, ny, nz):
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.sx = ny * nz
+
+    shape = property(lambda self: (self.nx, self.ny, self.nz))
+
+    def empty(self, dtype=torch.float64, zero=False):
+        return torch.zeros(self.shape, dtype=dtype)
+
+    def to_layout(self, a, dtype):
+        if isinstance(a, torch.Tensor):
+            return a.to(dtype).contiguous()
+        arr = np.asarray(a)
+        if dtype == torch.uint8:
+            arr = arr.astype(np.bool_).astype(np.uint8)
+        return torch.from_numpy(np.ascontiguousarray(arr)).to(dtype)
+
+
+class _Pack:
+    def __init__(self, coeff, dm, dv, q, variant):
+        self.d_coeff, self.d_dir_mask, self.d_dir_val, self.d_qflux, self.variant = coeff, dm, dv, q, variant
+
+
+def _flags(mask):
+    m = mask.astype(bool)
+    f = m.astype(np.uint8)
+    for ax in range(3):
+        lo = np.zeros_like(m); hi = np.zeros_like(m)
+        sl_hi = [slice(None)] * 3; sl_lo = [slice(None)] * 3
+        sl_hi[ax] = slice(1, None); sl_lo[ax] = slice(None, -1)
+        lo[tuple(sl_hi)] = m[tuple(sl_lo)]
+        hi[tuple(sl_lo)] = m[tuple(sl_hi)]
+        f |= ((m & lo).astype(np.uint8) << (1 + 2 * ax)) | ((m & hi).astype(np.uint8) << (2 + 2 * ax))
+    return f
+
+
+def _line_systems(axis, t_in, flags, pack, theta, gam, dt, Tinf):
+    """full-length rows (a, b, c, d) of every line along `axis`, arrays shaped like the field
+    (adi3d_gpu_coeff.py:173-187 with the neighbour tests taken from the flags, halo bits included)"""
+    R = t_in.numpy(); f = flags.numpy()
+    co = pack[0].numpy()
+    dm = pack[1].numpy().astype(bool) if pack[1] is not None else np.zeros(R.shape, bool)
+    dv = pack[2].numpy() if pack[2] is not None else np.zeros(R.shape)
+    q = pack[3].numpy() if pack[3] is not None else np.zeros(R.shape)
+    m = (f & 1).astype(bool)
+    L = ((f >> (1 + 2 * axis)) & 1).astype(bool)
+    H = ((f >> (2 + 2 * axis)) & 1).astype(bool)
+    fr = m & ~dm
+    tg = theta * gam
+    a = np.where(fr & L, -tg, 0.0); c = np.where(fr & H, -tg, 0.0)
+    b = np.where(fr, 1.0 + tg * (L.astype(float) + H.astype(float)) + dt * co, 1.0)
+    d = np.where(fr, R + dt * q + dt * co * Tinf, np.where(m & dm, dv, R))
+    return a, b, c, d
+
+
+def _dense(a, b, c):
+    n = len(b)
+    A = np.diag(b)
+    for i in range(1, n):
+        A[i, i - 1] = a[i]; A[i - 1, i] = c[i - 1]
+    return A
+
+
+class CpuEngine:
+    device = torch.device('cpu')
+
+    def layout(self, nx, ny, nz):
+        return CpuLayout(nx, ny, nz)
+
+    def vec(self, n):
+        return torch.zeros(n, dtype=torch.float64)
+
+    def build_flags(self, L, mask_ext):
+        return torch.from_numpy(_flags(mask_ext.numpy()))
+
+    def build_packs(self, L, mask_ext, dx, mat, dir_mask, dir_value, neumann, robin_h):
+        grid = orc.Grid3D(L.nx, L.ny, L.nz, dx, mask_ext.numpy().astype(bool))
+        packs = orc.precompute_coeff_packs_unified(grid, orc.Material(mat.rho, mat.cp, mat.k), dir_mask=dir_mask,
+                                                   dir_value=dir_value, neumann=neumann, robin_h=robin_h)
+        has_dir = dir_mask is not None and bool(np.any(dir_mask))
+        has_q = neumann is not None and any(v is not None for v in neumann.values())
+        variant = (0 if has_q else 2) if has_dir else (1 if has_q else 3)
+        t = torch.from_numpy
+        return tuple(_Pack(t(p.coeff), t(p.dir_mask.view(np.uint8)), t(p.dir_val), t(p.qflux), variant) for p in packs)
+
+    def explicit(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext):
+        mask = (flags_ext.numpy() & 1).astype(bool)
+        grid = orc.Grid3D(L.nx, L.ny, L.nz, dx, mask)
+        out_ext.copy_(torch.from_numpy(orc.explicit_rhs(np.nan_to_num(T_ext.numpy()), grid, orc.Material(1.0, 1.0, kappa),
+                                                        orc.Params(dt, theta))))
+
+    def sweep(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, xlo=None, xhi=None):
+        a, b, c, d = _line_systems(axis, t_in, flags, pack, theta, gam, dt, Tinf)
+        a = np.moveaxis(a, axis, -1).copy(); b = np.moveaxis(b, axis, -1).copy()
+        c = np.moveaxis(c, axis, -1).copy(); d = np.moveaxis(d, axis, -1).copy()
+        shp = d.shape
+        n = shp[-1]
+        a = a.reshape(-1, n); b = b.reshape(-1, n); c = c.reshape(-1, n); d = d.reshape(-1, n)
+        x = np.empty_like(d)
+        for l in range(d.shape[0]):
+            dd = d[l].copy()
+            if xlo is not None:
+                dd[0] -= a[l, 0] * float(xlo[l])
+            if xhi is not None:
+                dd[-1] -= c[l, -1] * float(xhi[l])
+            x[l] = np.linalg.solve(_dense(a[l], b[l], c[l]), dd)
+        t_out.copy_(torch.from_numpy(np.moveaxis(x.reshape(shp), -1, axis).copy()))
+
+    def condense(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, cond):
+        a, b, c, d = _line_systems(axis, t_in, flags, pack, theta, gam, dt, Tinf)
+        mv = lambda v: np.moveaxis(v, axis, -1).reshape(-1, v.shape[axis])
+        a, b, c, d = mv(a), mv(b), mv(c), mv(d)
+        nl, n = d.shape
+        out = cond.view(6, nl).numpy()
+        for l in range(nl):
+            Binv = np.linalg.inv(_dense(a[l], b[l], c[l]))
+            g = Binv @ d[l]
+            out[0, l] = g[0]; out[1, l] = a[l, 0] * Binv[0, 0]; out[2, l] = c[l, -1] * Binv[0, -1]
+            out[3, l] = g[-1]; out[4, l] = a[l, 0] * Binv[-1, 0]; out[5, l] = c[l, -1] * Binv[-1, -1]
+
+    def interface(self, cond_all, world, rank, nlines, xlo, xhi):
+        C = cond_all.view(world, 6, nlines).numpy()
+        lo = xlo.numpy(); hi = xhi.numpy()
+        for l in range(nlines):
+            # unknowns (f_0, l_0, f_1, l_1, ...):  f_r + aF_r l_{r-1} + cF_r f_{r+1} = gF_r ; same for l_r
+            A = np.eye(2 * world); rhs = np.zeros(2 * world)
+            for r in range(world):
+                gF, aF, cF, gL, aL, cL = C[r, :, l]
+                rhs[2 * r] = gF; rhs[2 * r + 1] = gL
+                if r > 0:
+                    A[2 * r, 2 * r - 1] += aF; A[2 * r + 1, 2 * r - 1] += aL
+                if r < world - 1:
+                    A[2 * r, 2 * r + 2] += cF; A[2 * r + 1, 2 * r + 2] += cL
+            z = np.linalg.solve(A, rhs)
+            lo[l] = z[2 * rank - 1] if rank > 0 else 0.0
+            hi[l] = z[2 * rank + 2] if rank < world - 1 else 0.0
