@@ -37,7 +37,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--n', type=int, default=512, help='cells per axis per GPU')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
-    ap.add_argument('--cpu-n', type=int, default=192, help='edge of the bounded CPU-baseline sample')
+    ap.add_argument('--cpu-n', type=int, default=256, help='edge of the bounded CPU-baseline sample')
     return ap.parse_args()
 
 
@@ -54,7 +54,7 @@ def cpu_baseline(n, seed=0):
     packs = orc.precompute_coeff_packs_unified(grid, mat, robin_h=500.0)
     T0 = np.random.default_rng(seed).uniform(20.0, 1000.0, shape)
     out = []
-    for omp, steps in ((False, 2), (True, 6)):
+    for omp, steps in ((False, 8), (True, 40)):
         orc.adi_run(T0, grid, mat, prm, packs, Tinf=20.0, nsteps=1, omp=omp)   # warm (page faults, OpenMP pool)
         t0 = time.perf_counter()
         orc.adi_run(T0, grid, mat, prm, packs, Tinf=20.0, nsteps=steps, omp=omp)
