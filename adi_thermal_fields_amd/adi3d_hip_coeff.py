@@ -280,6 +280,11 @@ class AxisCoeffPack:
         self.has_dir, self.has_q = bool(_has_dir), bool(_has_q)
         if self.has_dir and self.d_dir_val is None:
             self.d_dir_val = L.empty(zero=True)
+        # Set by precompute_coeff_packs_unified only: coeff/qflux are non-zero just on cells exposed along the
+        # pack's axis, so the sweep may skip loading them elsewhere.  Hand-built packs are read densely.
+        self.sparse_ok = False
+        self.exposed_fraction = 1.0    # fraction of cells exposed along the axis (for the byte accounting)
+        self.dir_fraction = 1.0
 
     @property
     def variant(self):
@@ -291,6 +296,18 @@ class AxisCoeffPack:
         if t is None:
             return np.zeros(self.layout.shape, dtype=dtype)
         return t.cpu().contiguous().numpy().astype(dtype, copy=False)
+
+    @property
+    def bytes_per_cell(self):
+        """HBM bytes per cell the sweep of this pack must move (its inputs + the output): the byte count of
+        the roofline (SURVEY.md 8(d) variant rule)."""
+        fe = self.exposed_fraction if self.sparse_ok else 1.0
+        b = 8.0 + 1.0 + 8.0 + 8.0 * fe                    # in, flags, out, coeff
+        if self.has_q:
+            b += 8.0 * fe
+        if self.has_dir:
+            b += 1.0 + 8.0 * (self.dir_fraction if self.sparse_ok else 1.0)
+        return b
 
     coeff = property(lambda self: self._host(self.d_coeff, np.float64))
     qflux = property(lambda self: self._host(self.d_qflux, np.float64))
@@ -372,8 +389,15 @@ def precompute_coeff_packs_unified(grid, mat, dir_mask=None, dir_value=None, neu
             d_dv = L.to_layout(dir_value, torch.float64)
     packs = tuple(AxisCoeffPack(coeff[a], d_dm, d_dv, qflux[a], _has_dir=has_dir, _has_q=has_q, _layout=L)
                   for a in range(3))
-    for p in packs:
+    fl = grid.d_flags
+    inmask = (fl & 1) == 1
+    ncell = float(grid.nx * grid.ny * grid.nz)
+    dfrac = float(d_dm.sum().item()) / ncell if has_dir else 0.0
+    for a, p in enumerate(packs):
         p.mask_version = grid.mask_version
+        p.sparse_ok = True
+        p.exposed_fraction = float((inmask & (((fl >> (1 + 2 * a)) & 3) != 3)).sum().item()) / ncell
+        p.dir_fraction = dfrac
     return packs
 
 
@@ -409,25 +433,26 @@ def adi_explicit_rhs(Tn, grid, mat, params):
     return _wrap(out, kind)
 
 
-def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None, xlo=None, xhi=None):
+def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None, xlo=None, xhi=None, dense=False):
     _, gam = _gam(grid, mat, params)
     _, work, wb = grid.scratch(2)
     v = pack.variant if variant is None else variant
     check(lib.adi_sweep(axis, v, _p(t_in), _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
                         _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
-                        params.theta, gam, params.dt, float(Tinf), _p(t_out), _p(xlo), _p(xhi),
+                        int(pack.sparse_ok and not dense), params.theta, gam, params.dt, float(Tinf), _p(t_out),
+                        _p(xlo), _p(xhi),
                         _p(work), wb, _stream()))
 
 
-def adi_sweep_axis(axis, stage_in, grid, mat, params, pack, Tinf=0.0, variant=None):
+def adi_sweep_axis(axis, stage_in, grid, mat, params, pack, Tinf=0.0, variant=None, dense=False):
     """sweep_axis0/1/2 of adi3d_numba_coeff.py:133-237 for one axis (stage entry point).
-    variant=None picks the leanest kernel the pack allows; pass _lib.SWEEP_GENERAL to force the
-    42 B/cell general-pack kernel."""
+    variant=None picks the leanest kernel the pack allows; variant=_lib.SWEEP_GENERAL with dense=True forces
+    the 42 B/cell general-pack kernel that reads every pack array in full, like the reference does."""
     t, kind = _as_state(stage_in, grid)
     if variant == _lib.SWEEP_GENERAL or (variant is None and pack.variant == _lib.SWEEP_GENERAL):
         _ensure_general(pack)
     out = grid.layout.empty()
-    _sweep_into(axis, t, out, grid, mat, params, pack, Tinf, variant)
+    _sweep_into(axis, t, out, grid, mat, params, pack, Tinf, variant, dense=dense)
     return _wrap(out, kind)
 
 
@@ -474,13 +499,13 @@ class StagedStepper:
 
     def __init__(self, grid, mat, params, packs, Tinf=0.0):
         self.grid, self.mat, self.params, self.packs, self.Tinf = grid, mat, params, packs, float(Tinf)
-        self.stage_bytes_per_cell = [_lib.EXPLICIT_BYTES_PER_CELL] + \
-            [_lib.SWEEP_BYTES_PER_CELL[p.variant] for p in packs]
+        self.stage_bytes_per_cell = [float(_lib.EXPLICIT_BYTES_PER_CELL)] + [p.bytes_per_cell for p in packs]
 
-    def sweep_into(self, axis, t_in, t_out, variant=None):
+    def sweep_into(self, axis, t_in, t_out, variant=None, dense=False):
         if variant == _lib.SWEEP_GENERAL:
             _ensure_general(self.packs[axis])
-        _sweep_into(axis, t_in, t_out, self.grid, self.mat, self.params, self.packs[axis], self.Tinf, variant)
+        _sweep_into(axis, t_in, t_out, self.grid, self.mat, self.params, self.packs[axis], self.Tinf, variant,
+                    dense=dense)
 
     def step(self, T, events=None):
         g, prm = self.grid, self.params

@@ -30,7 +30,16 @@ struct SweepScal {
     double tg;    // theta * gamma
     double dt;
     double Tinf;
+    int sparse;   // 1: coeff / qflux are non-zero only on cells exposed along the sweep axis (packs built by
+                  //    adi_build_coeffs), so they are loaded only there; dir_val only where dir_mask is set
 };
+
+// cell is in the mask and lacks at least one in-mask neighbour along the sweep axis: the only cells where
+// precompute_coeff_packs_unified writes a Robin coefficient or a Neumann flux for that axis (:93-99, :104-114)
+__device__ __forceinline__ bool axis_exposed(unsigned f, int lbit)
+{
+    return (f & 1u) && (((f >> lbit) & 3u) != 3u);
+}
 
 // Assemble one row of the full-length system (adi3d_gpu_coeff.py:173-187; numba form :147-162).
 //   m / mL / mR : cell, previous and next cell of the line are in the mask
@@ -139,13 +148,21 @@ __global__ __launch_bounds__(256) void k_sweep_contig(
     const long base = pi * L.sx + (line - pi * L.ny) * (long)n + r0;
 
     double vin[M], vco[M], vdv[M], vq[M];
-    load_rows_contig<M, VEC>(in, base, r0, n, active, vin);
-    load_rows_contig<M, VEC>(coeff, base, r0, n, active, vco);
-    if (HAS_DIR) load_rows_contig<M, VEC>(dval, base, r0, n, active, vdv);
-    if (HAS_Q) load_rows_contig<M, VEC>(qf, base, r0, n, active, vq);
     unsigned fb[M], db[M];
     load_bytes_contig<M, VEC>(flags, base, r0, n, active, fb);
     if (HAS_DIR) load_bytes_contig<M, VEC>(dmask, base, r0, n, active, db);
+    load_rows_contig<M, VEC>(in, base, r0, n, active, vin);
+    {
+        bool need = !s.sparse, needd = !s.sparse;
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            need = need || axis_exposed(fb[r], 5);
+            if (HAS_DIR) needd = needd || (db[r] != 0);
+        }
+        load_rows_contig<M, VEC>(coeff, base, r0, n, active && need, vco);
+        if (HAS_Q) load_rows_contig<M, VEC>(qf, base, r0, n, active && need, vq);
+        if (HAS_DIR) load_rows_contig<M, VEC>(dval, base, r0, n, active && needd, vdv);
+    }
 
     double a[M], b[M], c[M], d[M];
 #pragma unroll
@@ -217,14 +234,22 @@ __device__ __forceinline__ void load_segment_strided(
         const long p = base + (long)(r0 + r) * g.stride;
         fb[r] = ok ? flags[p] : 0u;
         vin[r] = ok ? in[p] : 0.0;
-        vco[r] = ok ? coeff[p] : 0.0;
-        if (HAS_DIR) vdv[r] = ok ? dval[p] : 0.0;
-        if (HAS_Q) vq[r] = ok ? qf[p] : 0.0;
+    }
+    bool dirb[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        const bool ok = active && (r0 + r) < g.n;
+        const long p = base + (long)(r0 + r) * g.stride;
+        const bool need = ok && (!s.sparse || axis_exposed(fb[r], g.lbit));
+        dirb[r] = false;
+        if (HAS_DIR) dirb[r] = ok && dmask[p] != 0;
+        vco[r] = need ? coeff[p] : 0.0;
+        if (HAS_Q) vq[r] = need ? qf[p] : 0.0;
+        if (HAS_DIR) vdv[r] = (ok && (!s.sparse || dirb[r])) ? dval[p] : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-        bool dir = false;
-        if (HAS_DIR) dir = active && (r0 + r) < g.n && dmask[base + (long)(r0 + r) * g.stride] != 0;
+        const bool dir = dirb[r];
         assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> g.lbit) & 1u, (fb[r] >> (g.lbit + 1)) & 1u, dir, vin[r],
                                      vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r], c[r], d[r]);
     }
@@ -343,14 +368,22 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_condense_strided(
             const long p = base + (long)(r0 + r) * g.stride;
             fb[r] = ok ? flags[p] : 0u;
             vin[r] = ok ? in[p] : 0.0;
-            vco[r] = ok ? coeff[p] : 0.0;
-            if (HAS_DIR) vdv[r] = ok ? dval[p] : 0.0;
-            if (HAS_Q) vq[r] = ok ? qf[p] : 0.0;
+        }
+        bool dirb[M];
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            const bool ok = active && (r0 + r) < g.n;
+            const long p = base + (long)(r0 + r) * g.stride;
+            const bool need = ok && (!s.sparse || axis_exposed(fb[r], g.lbit));
+            dirb[r] = false;
+            if (HAS_DIR) dirb[r] = ok && dmask[p] != 0;
+            vco[r] = need ? coeff[p] : 0.0;
+            if (HAS_Q) vq[r] = need ? qf[p] : 0.0;
+            if (HAS_DIR) vdv[r] = (ok && (!s.sparse || dirb[r])) ? dval[p] : 0.0;
         }
 #pragma unroll
         for (int r = 0; r < M; ++r) {
-            bool dir = false;
-            if (HAS_DIR) dir = active && (r0 + r) < g.n && dmask[base + (long)(r0 + r) * g.stride] != 0;
+            const bool dir = dirb[r];
             assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> g.lbit) & 1u, (fb[r] >> (g.lbit + 1)) & 1u, dir,
                                          vin[r], vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r],
                                          c[r], d[r]);
@@ -996,7 +1029,7 @@ static int variant_flags(int variant, bool *has_dir, bool *has_q)
 
 int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
               const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
-              long plane_stride, double theta, double gam, double dt, double Tinf, double *d_out,
+              long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
               const double *d_xlo, const double *d_xhi, void *d_work, size_t work_bytes, void *stream)
 {
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep: bad axis %d", axis);
@@ -1012,6 +1045,7 @@ int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags,
     s.tg = theta * gam;
     s.dt = dt;
     s.Tinf = Tinf;
+    s.sparse = sparse ? 1 : 0;
     hipStream_t st = as_stream(stream);
     int rc;
     if (has_dir && has_q) rc = sweep_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st);
@@ -1025,8 +1059,8 @@ int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags,
 
 int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
                        const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny,
-                       int nz, long plane_stride, double theta, double gam, double dt, double Tinf, double *d_cond,
-                       void *stream)
+                       int nz, long plane_stride, int sparse, double theta, double gam, double dt, double Tinf,
+                       double *d_cond, void *stream)
 {
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep_condense: bad axis %d", axis);
     bool has_dir, has_q;
@@ -1040,6 +1074,7 @@ int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t 
     s.tg = theta * gam;
     s.dt = dt;
     s.Tinf = Tinf;
+    s.sparse = sparse ? 1 : 0;
     hipStream_t st = as_stream(stream);
     if (has_dir && has_q) condense_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, L, s, d_cond, st);
     else if (has_q) condense_dispatch<false, true>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, d_qflux, L, s, d_cond, st);
@@ -1062,9 +1097,9 @@ int adi_interface_solve(const double *d_cond_all, int nranks, int rank, long nli
 
 int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b, const uint8_t *d_flags,
              const double *const *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
-             const double *const *d_qflux, int variant, int nx, int ny, int nz, long plane_stride, double dx,
-             double rho, double cp, double k, double dt, double theta, double Tinf, void *d_work, size_t work_bytes,
-             void *stream)
+             const double *const *d_qflux, int variant, int sparse, int nx, int ny, int nz, long plane_stride,
+             double dx, double rho, double cp, double k, double dt, double theta, double Tinf, void *d_work,
+             size_t work_bytes, void *stream)
 {
     ADI_REQUIRE(d_T_in && d_T_out && d_tmp_a && d_tmp_b && d_coeff, "adi_step: null argument");
     ADI_REQUIRE(d_tmp_a != d_tmp_b && d_tmp_a != d_T_in && d_tmp_b != d_T_in && d_T_out != d_tmp_a && d_T_out != d_T_in,
@@ -1075,11 +1110,11 @@ int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_t
     const double *q0 = d_qflux ? d_qflux[0] : nullptr, *q1 = d_qflux ? d_qflux[1] : nullptr, *q2 = d_qflux ? d_qflux[2] : nullptr;
     int rc = adi_explicit_rhs(d_T_in, d_flags, nx, ny, nz, plane_stride, dx, dt, kappa, theta, d_tmp_a, stream);
     if (rc) return rc;
-    rc = adi_sweep(0, variant, d_tmp_a, d_flags, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, plane_stride, theta, gam, dt, Tinf, d_tmp_b, nullptr, nullptr, d_work, work_bytes, stream);
+    rc = adi_sweep(0, variant, d_tmp_a, d_flags, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_b, nullptr, nullptr, d_work, work_bytes, stream);
     if (rc) return rc;
-    rc = adi_sweep(1, variant, d_tmp_b, d_flags, d_coeff[1], d_dir_mask, d_dir_val, q1, nx, ny, nz, plane_stride, theta, gam, dt, Tinf, d_tmp_a, nullptr, nullptr, d_work, work_bytes, stream);
+    rc = adi_sweep(1, variant, d_tmp_b, d_flags, d_coeff[1], d_dir_mask, d_dir_val, q1, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_a, nullptr, nullptr, d_work, work_bytes, stream);
     if (rc) return rc;
-    return adi_sweep(2, variant, d_tmp_a, d_flags, d_coeff[2], d_dir_mask, d_dir_val, q2, nx, ny, nz, plane_stride, theta, gam, dt, Tinf, d_T_out, nullptr, nullptr, d_work, work_bytes, stream);
+    return adi_sweep(2, variant, d_tmp_a, d_flags, d_coeff[2], d_dir_mask, d_dir_val, q2, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_T_out, nullptr, nullptr, d_work, work_bytes, stream);
 }
 
 int adi_masked_fill(double *d_T, const uint8_t *d_sel, size_t n, double value, void *stream)

@@ -261,7 +261,7 @@ int adi_ctx_step(adi_ctx *c, double rho, double cp, double k, double dt, double 
     for (int s = 0; s < nsteps; ++s) {
         const int nxt = c->cur ^ 1;
         int rc = adi_step(c->T[c->cur], c->T[nxt], c->tmp[0], c->tmp[1], c->flags, c->coeff, c->dir_mask, c->dir_val,
-                          c->qflux, c->variant, c->nx, c->ny, c->nz, c->sx, c->dx, rho, cp, k, dt, theta, Tinf, c->work,
+                          c->qflux, c->variant, 1, c->nx, c->ny, c->nz, c->sx, c->dx, rho, cp, k, dt, theta, Tinf, c->work,
                           c->work_bytes, c->stream);
         if (rc != ADI_OK) return rc;
         c->cur = nxt;

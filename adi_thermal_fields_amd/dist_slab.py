@@ -155,7 +155,7 @@ class HipEngine:
     def _args(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf):
         h = self.hip
         return (axis, variant, h._p(t_in), h._p(flags), h._p(pack[0]), h._p(pack[1]), h._p(pack[2]), h._p(pack[3]),
-                Li.nx, Li.ny, Li.nz, Li.sx, theta, gam, dt, float(Tinf))
+                Li.nx, Li.ny, Li.nz, Li.sx, 1, theta, gam, dt, float(Tinf))   # packs come from adi_build_coeffs: sparse ok
 
     def sweep(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, xlo=None, xhi=None):
         h = self.hip
@@ -246,9 +246,10 @@ class SlabStepper:
                                        ext(bc['dir_value'], 0.0), neumann, robin_h)
         self.variant = self.packs_ext[0].variant
         from . import _lib
-        self.stage_bytes_per_cell = [_lib.EXPLICIT_BYTES_PER_CELL,
-                                     2 * (_lib.SWEEP_BYTES_PER_CELL[self.variant] - 8) + 8,   # inputs read twice
-                                     _lib.SWEEP_BYTES_PER_CELL[self.variant], _lib.SWEEP_BYTES_PER_CELL[self.variant]]
+        bpc = [getattr(p, 'bytes_per_cell', float(_lib.SWEEP_BYTES_PER_CELL[self.variant])) for p in self.packs_ext]
+        self.stage_bytes_per_cell = [float(_lib.EXPLICIT_BYTES_PER_CELL),
+                                     (2 * (bpc[0] - 8) + 8) if self.world > 1 else bpc[0],   # pass A re-reads the inputs
+                                     bpc[1], bpc[2]]
 
         def interior_pack(p):
             return tuple(None if t is None else _interior(t) for t in (p.d_coeff, p.d_dir_mask, p.d_dir_val, p.d_qflux))

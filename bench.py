@@ -140,7 +140,7 @@ def main():
     kernels = {}
     for i, nm in enumerate(stage_names):
         gbs = bytes_per_cell[nm] * N / (mean_ms[i] * 1e-3) / 1e9
-        kernels[nm] = dict(ms=round(float(mean_ms[i]), 4), bytes_per_cell=bytes_per_cell[nm],
+        kernels[nm] = dict(ms=round(float(mean_ms[i]), 4), bytes_per_cell=round(bytes_per_cell[nm], 3),
                            achieved_gbs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
 
     if rank != 0:
@@ -159,7 +159,7 @@ def main():
         tin = grid.layout.to_layout(Tin, torch.float64)
         for it in range(13):
             e0.record()
-            stepper.sweep_into(2, tin, out, variant=_lib.SWEEP_GENERAL)
+            stepper.sweep_into(2, tin, out, variant=_lib.SWEEP_GENERAL, dense=True)
             e1.record(); e1.synchronize()
             if it >= 3:
                 ms.append(e0.elapsed_time(e1))

@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 2
+#define ADI_ABI_VERSION 3
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -107,11 +107,15 @@ int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, 
  * d_xlo / d_xhi (optional, dense, one value per line): value of the unknown just before the first / after
  * the last local row when the line continues on a neighbouring GPU (see adi_interface_solve); the coupling
  * itself is read from the halo bits of d_flags.  NULL for a stand-alone grid.
+ * sparse != 0 asserts the invariant of packs built by adi_build_coeffs -- coeff/qflux of this axis are zero
+ * except on cells that lack an in-mask neighbour along the axis -- so the kernel loads them only there
+ * (and dir_val only where dir_mask is set).  Pass 0 for hand-built packs.
  * d_work/work_bytes: scratch for lines longer than the in-register limit (adi_sweep_workspace_bytes).
  */
 int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
               const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux,
-              int nx, int ny, int nz, long plane_stride, double theta, double gam, double dt, double Tinf,
+              int nx, int ny, int nz, long plane_stride, int sparse,
+              double theta, double gam, double dt, double Tinf,
               double *d_out, const double *d_xlo, const double *d_xhi,
               void *d_work, size_t work_bytes, void *stream);
 int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, long plane_stride, size_t *bytes);
@@ -124,7 +128,7 @@ int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, long plane_strid
  */
 int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t *d_flags,
                        const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
-                       const double *d_qflux, int nx, int ny, int nz, long plane_stride,
+                       const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse,
                        double theta, double gam, double dt, double Tinf, double *d_cond, void *stream);
 /* d_cond_all: [nranks][6][nlines], the all-gathered pass-A output ordered by slab.  Solves the reduced
  * interface system of every line and writes this rank's boundary values for pass B (adi_sweep). */
@@ -138,7 +142,7 @@ int adi_interface_solve(const double *d_cond_all, int nranks, int rank, long nli
  */
 int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b,
              const uint8_t *d_flags, const double *const *d_coeff, const uint8_t *d_dir_mask,
-             const double *d_dir_val, const double *const *d_qflux, int variant,
+             const double *d_dir_val, const double *const *d_qflux, int variant, int sparse,
              int nx, int ny, int nz, long plane_stride, double dx, double rho, double cp, double k,
              double dt, double theta, double Tinf, void *d_work, size_t work_bytes, void *stream);
 

@@ -43,12 +43,12 @@ def main():
     ms, mn = timeit(lambda: adi.adi_explicit_rhs(T, grid, mat, prm))
     res['explicit'] = (ms, mn, 17 * N / mn / 1e6)
     for ax in range(3):
-        for v, nm in ((_lib.SWEEP_GENERAL, 'general'), (None, 'lean')):
-            ms, mn = timeit(lambda: adi.adi_sweep_axis(ax, T, grid, mat, prm, packs[ax], Tinf=20.0, variant=v))
-            bpc = 42 if v == 0 else _lib.SWEEP_BYTES_PER_CELL[packs[ax].variant]
+        for v, nm, dn in ((_lib.SWEEP_GENERAL, 'general', True), (None, 'lean_dense', True), (None, 'lean', False)):
+            ms, mn = timeit(lambda: adi.adi_sweep_axis(ax, T, grid, mat, prm, packs[ax], Tinf=20.0, variant=v, dense=dn))
+            bpc = 42 if v == 0 else (_lib.SWEEP_BYTES_PER_CELL[packs[ax].variant] if dn else packs[ax].bytes_per_cell)
             res['sweep%d_%s' % (ax, nm)] = (ms, mn, bpc * N / mn / 1e6)
     ms, mn = timeit(lambda: adi.adi_step_hip_coeff(T, grid, mat, prm, packs, Tinf=20.0))
-    res['step_lean'] = (ms, mn, (17 + 3 * 25) * N / mn / 1e6)
+    res['step_lean'] = (ms, mn, (17 + sum(p.bytes_per_cell for p in packs)) * N / mn / 1e6)
     for k, (ms, mn, gbs) in res.items():
         print('%-16s median %8.3f ms  min %8.3f ms  %8.1f GB/s (min)' % (k, ms, mn, gbs))
     print(json.dumps(res))

@@ -20,7 +20,7 @@ def test_header_symbols_exported_and_bound():
         assert n in _lib.SIGNATURES, 'ctypes binding missing for %s' % n
     for n in _lib.SIGNATURES:
         assert n in names, '%s bound but not declared in include/adi_hip.h' % n
-    assert _lib.lib.adi_abi_version() == 2
+    assert _lib.lib.adi_abi_version() == 3
 
 
 def test_argument_errors_without_gpu():
@@ -31,7 +31,7 @@ def test_argument_errors_without_gpu():
     with pytest.raises(ValueError, match='bad face'):
         _lib.check(_lib.lib.adi_exposed_mask(ctypes.c_void_p(8), 2, 2, 2, 0, 9, ctypes.c_void_p(8), None))
     with pytest.raises(ValueError):
-        _lib.check(_lib.lib.adi_sweep(5, 0, None, None, None, None, None, None, 1, 1, 1, 0, 0.5, 1.0, 1.0, 0.0,
+        _lib.check(_lib.lib.adi_sweep(5, 0, None, None, None, None, None, None, 1, 1, 1, 0, 0, 0.5, 1.0, 1.0, 0.0,
                                       None, None, None, None, 0, None))
     with pytest.raises(ValueError, match='unknown zbc.kind_bot'):
         h = ctypes.c_void_p()

@@ -46,9 +46,10 @@ def test_cart_vs_golden(hip, name):
         assert np.array_equal(out['T_final'][off], c['T0'][off])
 
 
-@pytest.mark.parametrize('variant', [0, None])
-def test_cart_stages_vs_golden(hip, variant):
-    """every stage alone, fed with the reference's own previous stage; variant 0 forces the general-pack kernel"""
+@pytest.mark.parametrize('variant,dense', [(0, True), (0, False), (None, False)])
+def test_cart_stages_vs_golden(hip, variant, dense):
+    """every stage alone, fed with the reference's own previous stage; variant 0 + dense forces the
+    general-pack kernel that reads every array in full"""
     c = cases.cart_case(cases.CART_STAGE_CASE)
     g = golden('cart', cases.CART_STAGE_CASE)
     grid = hip.Grid3D(*c['shape'], c['dx'], c['mask'])
@@ -59,7 +60,7 @@ def test_cart_stages_vs_golden(hip, variant):
     assert np.array_equal(R0, g['R0'])          # explicit stage is bit-exact (contraction off, same order)
     prev = {'U': 'R0', 'V': 'U', 'W': 'V'}
     for ax, nm in enumerate('UVW'):
-        got = hip.adi_sweep_axis(ax, g[prev[nm]], grid, mat, prm, packs[ax], Tinf=c['Tinf'], variant=variant)
+        got = hip.adi_sweep_axis(ax, g[prev[nm]], grid, mat, prm, packs[ax], Tinf=c['Tinf'], variant=variant, dense=dense)
         assert rel_linf(got, g[nm]) <= TOL, (nm, rel_linf(got, g[nm]))
 
 
