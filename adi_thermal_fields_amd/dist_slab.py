@@ -138,11 +138,11 @@ class HipEngine:
                                                 self.hip._stream()))
         return flags
 
-    def build_packs(self, L, mask_ext, dx, mat, dir_mask, dir_value, neumann, robin_h):
+    def build_packs(self, L, mask_ext, flags_ext, dx, mat, dir_mask, dir_value, neumann, robin_h):
         """precompute_coeff_packs_unified on the extended slab; returns packs whose arrays are extended too."""
         g = self.hip.Grid3D.__new__(self.hip.Grid3D)
         g.nx, g.ny, g.nz, g.dx, g.layout = L.nx, L.ny, L.nz, float(dx), L
-        g._mask, g._d_mask, g._d_flags, g._scratch, g.mask_version = None, mask_ext, None, None, 0
+        g._mask, g._d_mask, g._d_flags, g._scratch, g.mask_version = None, mask_ext, flags_ext, None, 0
         g.sync_mask = lambda: mask_ext            # the device mask (with halos) is authoritative here
         return self.hip.precompute_coeff_packs_unified(g, mat, dir_mask=dir_mask, dir_value=dir_value,
                                                        neumann=neumann, robin_h=robin_h)
@@ -242,7 +242,7 @@ class SlabStepper:
             robin_h = {f: ext(v, 0.0) for f, v in robin_h.items()}
         else:
             robin_h = ext(robin_h, 0.0)
-        self.packs_ext = E.build_packs(L, d_mask, self.dx, self.mat, ext(bc['dir_mask'], False),
+        self.packs_ext = E.build_packs(L, d_mask, self.flags_ext, self.dx, self.mat, ext(bc['dir_mask'], False),
                                        ext(bc['dir_value'], 0.0), neumann, robin_h)
         self.variant = self.packs_ext[0].variant
         from . import _lib

@@ -84,7 +84,7 @@ class CpuEngine:
     def build_flags(self, L, mask_ext):
         return torch.from_numpy(_flags(mask_ext.numpy()))
 
-    def build_packs(self, L, mask_ext, dx, mat, dir_mask, dir_value, neumann, robin_h):
+    def build_packs(self, L, mask_ext, flags_ext, dx, mat, dir_mask, dir_value, neumann, robin_h):
         grid = orc.Grid3D(L.nx, L.ny, L.nz, dx, mask_ext.numpy().astype(bool))
         packs = orc.precompute_coeff_packs_unified(grid, orc.Material(mat.rho, mat.cp, mat.k), dir_mask=dir_mask,
                                                    dir_value=dir_value, neumann=neumann, robin_h=robin_h)
