@@ -201,9 +201,7 @@ class SlabStepper:
         self._ext_bufs = [self.Lext.empty(), self.Lext.empty()]
         self._cur = 0
         self._tmp = [self.Lext.empty(), self.Lext.empty()]
-        self._cond = E.vec(6 * self.nlines)
-        self._cond_all = E.vec(6 * self.nlines * self.world)
-        self._xlo, self._xhi = E.vec(self.nlines), E.vec(self.nlines)
+        self._chunk_list = None
         self.set_mask(mask_local)
 
     @classmethod
@@ -270,6 +268,54 @@ class SlabStepper:
         _interior(buf).copy_(src)
         return buf
 
+    def _chunks(self):
+        """(j0, j1) ranges: the lines of the sharded sweep are cut along j so that each chunk is a sub-box"""
+        if getattr(self, '_chunk_list', None) is None:
+            nch = 4 if (self.ny >= 32) else 1
+            edges = [round(i * self.ny / nch) for i in range(nch + 1)]
+            self._chunk_list = [(edges[i], edges[i + 1]) for i in range(nch) if edges[i + 1] > edges[i]]
+            E = self.engine
+            self._chunk_bufs = []
+            for j0, j1 in self._chunk_list:
+                nl = (j1 - j0) * self.nz
+                self._chunk_bufs.append(dict(L=E.layout(self.nxl, j1 - j0, self.nz), nl=nl, cond=E.vec(6 * nl),
+                                             cond_all=E.vec(6 * nl * self.world), xlo=E.vec(nl), xhi=E.vec(nl)))
+            self._use_streams = (E.device.type == 'cuda') and isinstance(self.comm, TorchDistComm)
+            if self._use_streams:
+                self._comm_stream = torch.cuda.Stream(device=E.device)
+        return self._chunk_list
+
+    def _axis0_distributed(self, Ai, Bi, gam):
+        E, prm, v = self.engine, self.params, self.variant
+        chunks = self._chunks()
+        fl = self.flags_int
+        pk = self.packs_int[0]
+
+        def sub(t, j0, j1):
+            return None if t is None else t[:, j0:j1, :]
+        use_streams = self._use_streams
+        main = torch.cuda.current_stream() if use_streams else None
+        ev_cond, ev_ag = [], []
+        for (j0, j1), cb in zip(chunks, self._chunk_bufs):           # pass A for every chunk
+            E.condense(0, v, cb['L'], sub(Ai, j0, j1), sub(fl, j0, j1), tuple(sub(t, j0, j1) for t in pk),
+                       prm.theta, gam, prm.dt, self.Tinf, cb['cond'])
+            if use_streams:
+                e = torch.cuda.Event(); e.record(main); ev_cond.append(e)
+        if use_streams:
+            with torch.cuda.stream(self._comm_stream):                 # all-gathers on the second stream
+                for cb, e in zip(self._chunk_bufs, ev_cond):
+                    self._comm_stream.wait_event(e)
+                    self.comm.all_gather(cb['cond_all'], cb['cond'])
+                    e2 = torch.cuda.Event(); e2.record(self._comm_stream); ev_ag.append(e2)
+        for i, ((j0, j1), cb) in enumerate(zip(chunks, self._chunk_bufs)):   # interface + pass B per chunk
+            if use_streams:
+                main.wait_event(ev_ag[i])
+            else:
+                self.comm.all_gather(cb['cond_all'], cb['cond'])
+            E.interface(cb['cond_all'], self.world, self.rank, cb['nl'], cb['xlo'], cb['xhi'])
+            E.sweep(0, v, cb['L'], sub(Ai, j0, j1), sub(fl, j0, j1), tuple(sub(t, j0, j1) for t in pk), prm.theta, gam,
+                    prm.dt, self.Tinf, sub(Bi, j0, j1), cb['xlo'], cb['xhi'])
+
     def step(self, T, events=None):
         E, prm, mat = self.engine, self.params, self.mat
         kappa = mat.k / (mat.rho * mat.cp)                       # adi3d_numba_coeff.py:292
@@ -291,12 +337,10 @@ class SlabStepper:
         mark(1)
         Ai, Bi, Oi = _interior(A), _interior(B), _interior(nxt)
         v, Li, fl = self.variant, self.Lint, self.flags_int
-        # 3. distributed axis-0 sweep
+        # 3. distributed axis-0 sweep, pipelined over chunks of lines (ranges of j): the all-gather of chunk c
+        #    runs on a second stream while chunk c+1 is condensed and chunk c-1 is solved
         if self.world > 1:
-            E.condense(0, v, Li, Ai, fl, self.packs_int[0], prm.theta, gam, prm.dt, self.Tinf, self._cond)
-            self.comm.all_gather(self._cond_all, self._cond)
-            E.interface(self._cond_all, self.world, self.rank, self.nlines, self._xlo, self._xhi)
-            E.sweep(0, v, Li, Ai, fl, self.packs_int[0], prm.theta, gam, prm.dt, self.Tinf, Bi, self._xlo, self._xhi)
+            self._axis0_distributed(Ai, Bi, gam)
         else:
             E.sweep(0, v, Li, Ai, fl, self.packs_int[0], prm.theta, gam, prm.dt, self.Tinf, Bi)
         mark(2)

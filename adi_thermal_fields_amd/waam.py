@@ -1,0 +1,170 @@
+"""waam -- the layer-birth / moving-deposit time loops of the reference's WAAM drivers, backend-agnostic.
+
+The loops are restated from waam_from_stl_v7_mm.py (layers :436-456, birth times :458-471, activate_layer
+:487-495, event loop :515-550) and single_track_on_plate.py:150-177 (column-by-column deposit).  They drive ANY
+module with the reference's operator surface (`Grid3D`, `Material`, `Params`,
+`precompute_coeff_packs_unified`, `adi_step_numba_coeff`): the HIP backend in production, the CPU oracle in
+the parity tests.  STL loading / voxelisation (trimesh) is out of scope; `synthetic_head_mask` supplies the
+formula-generated stand-in for the missing `11091_FemaleHead_v4.stl`.
+
+With the HIP backend the temperature stays in HBM for the whole run: births are a masked fill on the
+device, the mask/pack rebuild is one upload (1 B/cell) plus two kernels, frames download only at output times.
+"""
+import math
+
+import numpy as np
+
+__all__ = ['synthetic_head_mask', 'plan_layers', 'birth_times', 'run_layer_birth', 'run_single_track']
+
+
+def synthetic_head_mask(nx, ny, nz):
+    """Union of an ellipsoid (semi-axes 0.35/0.42/0.45 of the box, centred at 0.5/0.5/0.55) and a neck
+    cylinder (radius 0.16 of the box, lower 40 %), by formula."""
+    x = (np.arange(nx) + 0.5) / nx - 0.5
+    y = (np.arange(ny) + 0.5) / ny - 0.5
+    z = (np.arange(nz) + 0.5) / nz
+    X, Y, Z = np.meshgrid(x, y, z, indexing='ij')
+    ell = (X / 0.35) ** 2 + (Y / 0.42) ** 2 + ((Z - 0.55) / 0.45) ** 2 <= 1.0
+    neck = (X ** 2 + Y ** 2 <= 0.16 ** 2) & (Z <= 0.4)
+    return ell | neck
+
+
+def plan_layers(mask_full, n_per_layer):
+    """waam_from_stl_v7_mm.py:436-456: (ks, ke) plane ranges along axis 2, skipping empty planes."""
+    k_indices = np.where(mask_full.any(axis=(0, 1)))[0]
+    if k_indices.size == 0:
+        raise RuntimeError("empty voxel model")
+    kmin, kmax = int(k_indices.min()), int(k_indices.max())
+    n_per_layer = max(1, int(n_per_layer))
+    layers = []
+    ks = kmin
+    while ks <= kmax:
+        while ks <= kmax and not mask_full[:, :, ks].any():
+            ks += 1
+        if ks > kmax:
+            break
+        ke = min(kmax, ks + n_per_layer - 1)
+        while ke >= ks and not mask_full[:, :, ke].any():
+            ke -= 1
+        if ke < ks:
+            ks += 1
+            continue
+        layers.append((ks, ke))
+        ks = ke + 1
+    return layers
+
+
+def birth_times(mask_full, layers, dx, bead_width, scan_speed, eta_fill=1.0):
+    """waam_from_stl_v7_mm.py:458-471: cumulative deposition time per layer from its mean cross-section."""
+    times, t = [], 0.0
+    for ks, ke in layers:
+        areas = [float(mask_full[:, :, k].sum()) * dx * dx for k in range(ks, ke + 1)]
+        A = float(np.mean(areas)) if areas else 0.0
+        L = (A / max(bead_width, 1e-12)) * max(eta_fill, 1.0)
+        t += float(L / max(scan_speed, 1e-12))
+        times.append(t)
+    return times
+
+
+def _is_device_backend(backend):
+    return hasattr(backend, 'to_device')
+
+
+def _step(backend, T, grid, mat, params, packs, Tinf):
+    fn = getattr(backend, 'adi_step_hip_coeff', None) or backend.adi_step_numba_coeff
+    return fn(T, grid, mat, params, packs, Tinf=Tinf)
+
+
+def _birth(backend, T, grid, newborn, Ts):
+    """T[newborn] = Ts (waam_from_stl_v7_mm.py:489-493)"""
+    if _is_device_backend(backend) and hasattr(T, 'fill_where'):
+        import torch
+        T.fill_where(grid.layout.to_layout(newborn, torch.uint8), Ts)
+    else:
+        T[newborn] = Ts
+    return T
+
+
+def run_layer_birth(backend, mask_full, dx, mat_args, h, Tinf, Ts, theta, cfl, layers, times_birth, times_out,
+                    on_frame=None, device_resident=True):
+    """The event loop of waam_from_stl_v7_mm.py:515-550.  Returns (T_final as NumPy, number of ADI steps)."""
+    nx, ny, nz = mask_full.shape
+    mask_act = np.zeros_like(mask_full, dtype=bool)
+    grid = backend.Grid3D(nx, ny, nz, dx, mask_act)
+    mat = backend.Material(*mat_args)
+    params = backend.Params(dt=1e-3, theta=theta)
+    alpha = mat_args[2] / (mat_args[0] * mat_args[1])
+    dt_cap = cfl * dx * dx / alpha
+    T = np.full((nx, ny, nz), float(Tinf), dtype=np.float64)
+    if device_resident and _is_device_backend(backend):
+        T = backend.to_device(T)
+    robin = {f: h for f in ('x-', 'x+', 'y-', 'y+', 'z-', 'z+')}
+
+    def build_packs():
+        return backend.precompute_coeff_packs_unified(grid, mat, dir_mask=None, dir_value=None, neumann=None,
+                                                      robin_h=robin, robin_Tinf=Tinf)
+    packs = build_packs()
+    nsteps = 0
+    next_birth, t_now = 0, 0.0
+
+    def advance(seg):
+        nonlocal T, nsteps
+        nsub = max(1, int(math.ceil(seg / dt_cap)))
+        params.dt = max(seg / nsub, 1e-15)
+        for _ in range(nsub):
+            T = _step(backend, T, grid, mat, params, packs, Tinf)
+        nsteps += nsub
+
+    events = sorted(set(list(times_out) + list(times_birth)))
+    for te in events:
+        while next_birth < len(times_birth) and times_birth[next_birth] <= te + 1e-15:
+            t_b = times_birth[next_birth]
+            seg = max(0.0, t_b - t_now)
+            if seg > 1e-15 and mask_act.any():       # no ADI steps while nothing is active (:524)
+                advance(seg)
+            t_now = t_b
+            ks, ke = layers[next_birth]
+            born = np.zeros_like(mask_full, dtype=bool)
+            born[:, :, ks:ke + 1] = mask_full[:, :, ks:ke + 1]
+            newborn = born & (~mask_act)
+            if newborn.any():
+                T = _birth(backend, T, grid, newborn, Ts)
+            mask_act |= born
+            grid.mask = mask_act                       # :494-495
+            packs = build_packs()                      # :534
+            next_birth += 1
+        seg = max(0.0, te - t_now)
+        if seg > 1e-15 and mask_act.any():
+            advance(seg)
+        t_now = te
+        if on_frame is not None and any(abs(te - to) <= 1e-12 for to in times_out):
+            on_frame(t_now, np.asarray(T), mask_act.copy())
+    return np.asarray(T), nsteps
+
+
+def run_single_track(backend, plate_mask, track_box, dx, mat_args, h, Tinf, T_track, theta, dt, t_step,
+                     device_resident=True):
+    """single_track_on_plate.py:150-177: the deposit advances one column per t_step along axis 1; packs are
+    rebuilt after every column.  track_box = (x0, x1, z0, z1, n_columns)."""
+    x0, x1, z0, z1, ncol = track_box
+    nx, ny, nz = plate_mask.shape
+    mask = plate_mask.copy()
+    grid = backend.Grid3D(nx, ny, nz, dx, mask)
+    mat = backend.Material(*mat_args)
+    params = backend.Params(dt=dt, theta=theta)
+    T = np.full((nx, ny, nz), float(Tinf), dtype=np.float64)
+    if device_resident and _is_device_backend(backend):
+        T = backend.to_device(T)
+    robin = {f: h for f in ('x-', 'x+', 'y-', 'y+', 'z-', 'z+')}
+    for yi in range(ncol):
+        mask[x0:x1, yi:yi + 1, z0:z1] = True
+        grid.mask = mask
+        packs = backend.precompute_coeff_packs_unified(grid, mat, robin_h=robin, robin_Tinf=Tinf)
+        T[x0:x1, yi:yi + 1, z0:z1] = T_track
+        n_sub = max(1, int(math.ceil(t_step / dt)))
+        dt_orig = params.dt
+        params.dt = t_step / n_sub
+        for _ in range(n_sub):
+            T = _step(backend, T, grid, mat, params, packs, Tinf)
+        params.dt = dt_orig
+    return np.asarray(T)

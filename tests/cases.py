@@ -98,6 +98,13 @@ def cart_case(name):
         births = [(4, 8), (8, 12), (12, 16)]  # z-ranges activated in turn
         c.update(shape=s, dx=dx, mask=base, T0=np.where(base, 200.0, 20.0), robin_h=40.0, full_mask=full,
                  births=births, Ts=1000.0, dt=20.0 * dx * dx / _alpha(mat), nsteps=2)  # nsteps per layer
+    elif name == 'slab_chunks':  # ny >= 32: the distributed axis-0 sweep is pipelined over 4 chunks of lines
+        s = (9, 34, 6)
+        rng = np.random.default_rng(31)
+        mask = rng.random(s) > 0.15
+        dx = 1e-3
+        c.update(shape=s, dx=dx, mask=mask, T0=rng.uniform(20.0, 900.0, s), robin_h={'x-': 200.0, 'x+': 350.0, 'z+': 80.0},
+                 neumann={'y-': 2e5}, dt=120.0 * dx * dx / _alpha(mat), nsteps=2)
     elif name == 'config1_64':  # BASELINE.json configs[0] / SURVEY.md 8(d) config 1
         s = (64, 64, 64)
         dm = np.zeros(s, bool); dm[:, :, 0] = True; dm[:, :, -1] = True

@@ -47,7 +47,8 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,case_name', [(2, 'holes_mixed'), (3, 'kat2'), (2, 'dirichlet_only_gamma07')])
+@pytest.mark.parametrize('world,case_name', [(2, 'holes_mixed'), (3, 'kat2'), (2, 'dirichlet_only_gamma07'),
+                                             (2, 'slab_chunks')])
 def test_slab_decomposition_matches_single_domain(world, case_name):
     sys.path.insert(0, os.path.dirname(HERE))
     from oracle import adi_oracle as orc

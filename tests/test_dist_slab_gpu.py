@@ -50,7 +50,7 @@ def _run_slabs(c, world, sizes, nsteps):
     return np.concatenate(out, axis=0)
 
 
-@pytest.mark.parametrize('world,case_name', [(2, 'holes_mixed'), (3, 'kat2'), (4, 'long_line_70'),
+@pytest.mark.parametrize('world,case_name', [(2, 'holes_mixed'), (3, 'kat2'), (4, 'long_line_70'), (3, 'slab_chunks'),
                                              (2, 'dirichlet_only_gamma07')])
 def test_slabs_match_single_domain(world, case_name):
     from oracle import adi_oracle as orc

@@ -1,0 +1,72 @@
+"""The WAAM layer-birth and single-track loops (adi_thermal_fields_amd.waam): host logic on CPU, and the
+HIP backend against the oracle driven through the very same loop on the GPU."""
+import numpy as np
+import pytest
+
+from helpers import rel_linf
+
+STEEL = (7800.0, 490.0, 54.0)
+
+
+def _setup(shape):
+    from adi_thermal_fields_amd import waam
+    mask = waam.synthetic_head_mask(*shape)
+    layers = waam.plan_layers(mask, 2)
+    dx = 1e-3
+    times = waam.birth_times(mask, layers, dx, bead_width=4e-3, scan_speed=0.02)
+    return waam, mask, layers, dx, times
+
+
+def test_layers_and_times_host_logic():
+    waam, mask, layers, dx, times = _setup((24, 24, 30))
+    covered = np.zeros(30, bool)
+    for ks, ke in layers:
+        assert ks <= ke and mask[:, :, ks].any() and mask[:, :, ke].any()
+        covered[ks:ke + 1] = True
+    assert np.array_equal(covered, mask.any(axis=(0, 1)))        # every non-empty plane is born exactly once
+    assert all(b[0] == a[1] + 1 for a, b in zip(layers, layers[1:]))
+    assert len(times) == len(layers) and all(t2 > t1 for t1, t2 in zip(times, times[1:]))
+    with pytest.raises(RuntimeError):
+        waam.plan_layers(np.zeros((3, 3, 3), bool), 2)
+
+
+def test_layer_birth_loop_on_oracle_runs():
+    """the loop itself is backend-agnostic: run it on the CPU oracle (tiny grid)"""
+    from oracle import adi_oracle as orc
+    waam, mask, layers, dx, times = _setup((10, 10, 12))
+    frames = []
+    T, nsteps = waam.run_layer_birth(orc, mask, dx, STEEL, 40.0, 20.0, 1000.0, 0.5, 2000.0, layers, times,
+                                     [0.0, times[-1]], on_frame=lambda t, T, m: frames.append((t, T.max(), m.sum())))
+    assert nsteps >= len(layers) - 1 and len(frames) == 2
+    assert np.all(T[~mask] == 20.0)                  # never-born cells untouched
+    assert 20.0 < T[mask].max() <= 1000.0 + 1e-9
+
+
+@pytest.mark.gpu
+def test_layer_birth_hip_matches_oracle():
+    """BASELINE.json configs[4] shape (voxel mask + layer birth, pack rebuild per birth) on a 24x24x30 shrink"""
+    from oracle import adi_oracle as orc
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    waam, mask, layers, dx, times = _setup((24, 24, 30))
+    outs = [0.0, 0.5 * times[-1], times[-1]]
+    want, n1 = waam.run_layer_birth(orc, mask, dx, STEEL, 40.0, 20.0, 1000.0, 0.5, 2000.0, layers, times, outs)
+    fr = []
+    got, n2 = waam.run_layer_birth(hip, mask, dx, STEEL, 40.0, 20.0, 1000.0, 0.5, 2000.0, layers, times, outs,
+                                   on_frame=lambda t, T, m: fr.append(T))
+    assert n1 == n2 and len(fr) == 3
+    assert rel_linf(got, want) <= 1e-10, rel_linf(got, want)
+    assert np.array_equal(got[~mask], want[~mask])
+
+
+@pytest.mark.gpu
+def test_single_track_hip_matches_oracle():
+    from oracle import adi_oracle as orc
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from adi_thermal_fields_amd import waam
+    shape = (14, 18, 10)
+    plate = np.zeros(shape, bool); plate[:, :, :4] = True
+    box = (5, 9, 4, 7, 12)
+    args = (plate, box, 1e-3, STEEL, 25.0, 20.0, 1500.0, 0.5, 0.02, 0.05)
+    want = waam.run_single_track(orc, *args)
+    got = waam.run_single_track(hip, *args)
+    assert rel_linf(got, want) <= 1e-10, rel_linf(got, want)
