@@ -126,8 +126,8 @@ class HipEngine:
         self.hip, self._lib, self.lib, self.check = hip, _lib, _lib.lib, _lib.check
         self.device = hip._device()
 
-    def layout(self, nx, ny, nz):
-        return self.hip.Layout(nx, ny, nz)
+    def layout(self, nx, ny, nz, sx=None):
+        return self.hip.Layout(nx, ny, nz, sx)
 
     def vec(self, n):
         return torch.empty(n, dtype=torch.float64, device=self.device)
@@ -278,7 +278,7 @@ class SlabStepper:
             self._chunk_bufs = []
             for j0, j1 in self._chunk_list:
                 nl = (j1 - j0) * self.nz
-                self._chunk_bufs.append(dict(L=E.layout(self.nxl, j1 - j0, self.nz), nl=nl, cond=E.vec(6 * nl),
+                self._chunk_bufs.append(dict(L=E.layout(self.nxl, j1 - j0, self.nz, self.Lint.sx), nl=nl, cond=E.vec(6 * nl),
                                              cond_all=E.vec(6 * nl * self.world), xlo=E.vec(nl), xhi=E.vec(nl)))
             self._use_streams = (E.device.type == 'cuda') and isinstance(self.comm, TorchDistComm)
             if self._use_streams:

@@ -75,7 +75,7 @@ def _dense(a, b, c):
 class CpuEngine:
     device = torch.device('cpu')
 
-    def layout(self, nx, ny, nz):
+    def layout(self, nx, ny, nz, sx=None):
         return CpuLayout(nx, ny, nz)
 
     def vec(self, n):
