@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Per-rank compute cost of the slab-decomposed step on ONE GPU: the communicator is faked (the rank talks to
+copies of itself), so the timing contains every kernel a rank of an N-GPU run executes (halo-extended explicit
+stage, pass A, interface solve, pass B, local sweeps) but no wire time.  Upper bound on weak-scaling efficiency
+= single-domain step time / this time."""
+import sys, time
+import numpy as np
+import torch
+sys.path.insert(0, '.')
+import adi_thermal_fields_amd.adi3d_hip_coeff as adi
+from adi_thermal_fields_amd import dist_slab
+
+
+class FakeComm:
+    def __init__(self, world, rank):
+        self.world, self.rank = world, rank
+
+    def exchange_planes(self, send_lo, send_hi, recv_lo, recv_hi):
+        if self.rank > 0:
+            recv_lo.copy_(send_lo)
+        if self.rank < self.world - 1:
+            recv_hi.copy_(send_hi)
+
+    def all_gather(self, out, inp):
+        out.view(self.world, -1).copy_(inp.view(1, -1).expand(self.world, -1))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    mat = adi.Material(7800.0, 490.0, 54.0)
+    alpha = mat.k / (mat.rho * mat.cp)
+    dx = 5e-4
+    prm = adi.Params(200.0 * dx * dx / alpha, 0.5)
+    dev = torch.device('cuda')
+    T = adi.DeviceField(torch.rand((n, n, n), dtype=torch.float64, device=dev) * 980 + 20)
+    st = dist_slab.SlabStepper(np.ones((n, n, n), bool), dx, mat, prm, 20.0, robin_h=500.0,
+                               comm=FakeComm(world, world // 2))
+    for _ in range(3):
+        T = st.step(T)
+    torch.cuda.synchronize()
+    K = 10
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(K)]
+    t0 = time.perf_counter()
+    for s in range(K):
+        T = st.step(T, events=ev[s])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K * 1e3
+    ms = np.array([[ev[s][i].elapsed_time(ev[s][i + 1]) for i in range(4)] for s in range(K)]).mean(axis=0)
+    print('per-rank step %.3f ms (wall); stages %s' % (dt, dict(zip(st.stage_names, np.round(ms, 3)))))
+
+
+if __name__ == '__main__':
+    main()
