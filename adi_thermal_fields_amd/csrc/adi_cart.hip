@@ -134,7 +134,7 @@ template <int M, bool VEC, bool HAS_DIR, bool HAS_Q>
 __global__ __launch_bounds__(256) void k_sweep_contig(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    double *__restrict__ out, Lay L, int Lp, SweepScal s)
+    double *__restrict__ out, Lay L, int Lp, SweepScal s, UniC<M> U)
 {
     const int n = L.nz;
     const long nlines = (long)L.nx * L.ny;
@@ -164,15 +164,38 @@ __global__ __launch_bounds__(256) void k_sweep_contig(
         if (HAS_DIR) load_rows_contig<M, VEC>(dval, base, r0, n, active && needd, vdv);
     }
 
-    double a[M], b[M], c[M], d[M];
+    // uniform-interior fast path (wave-uniform decision): rows 1..M-2 have both z-neighbours in the mask and
+    // are not Dirichlet; row 0 may start a line or carry a Robin coefficient; the separator row is general
+    bool lane_fast = s.sparse != 0;
+    {
+        const unsigned FULL = 1u | (3u << 5), ROW0 = 1u | (1u << 6);
+        lane_fast = lane_fast && ((fb[0] & ROW0) == ROW0) && !(HAS_DIR && db[0] != 0);
 #pragma unroll
-    for (int r = 0; r < M; ++r)   // flags: bit0 cell in mask, bit5 / bit6 the z- / z+ neighbour is in the mask
-        assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> 5) & 1u, (fb[r] >> 6) & 1u, HAS_DIR && db[r] != 0, vin[r],
-                                     vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r], c[r], d[r]);
-
+        for (int r = 1; r < M - 1; ++r) lane_fast = lane_fast && ((fb[r] & FULL) == FULL) && !(HAS_DIR && db[r] != 0);
+    }
+    const bool fast = __all(lane_fast);
+    double a[M], b[M], c[M], d[M];
     double ip[M - 1];
     Cond k;
-    condense<M>(a, b, c, d, ip, k);
+    double kappa = 0.0, a0 = 0.0;
+    if (fast) {
+        double b0, c0;
+        assemble_row<HAS_DIR, HAS_Q>(fb[0] & 1u, (fb[0] >> 5) & 1u, (fb[0] >> 6) & 1u, false, vin[0], vco[0], 0.0,
+                                     HAS_Q ? vq[0] : 0.0, s, a0, b0, c0, d[0]);
+        assemble_row<HAS_DIR, HAS_Q>(fb[M - 1] & 1u, (fb[M - 1] >> 5) & 1u, (fb[M - 1] >> 6) & 1u,
+                                     HAS_DIR && db[M - 1] != 0, vin[M - 1], vco[M - 1], HAS_DIR ? vdv[M - 1] : 0.0,
+                                     HAS_Q ? vq[M - 1] : 0.0, s, a[M - 1], b[M - 1], c[M - 1], d[M - 1]);
+#pragma unroll
+        for (int r = 1; r < M - 1; ++r) d[r] = vin[r];   // regular rows: no coefficient, no flux -> rhs = in
+        condense_uniform<M>(U, a0, b0, d, k, kappa);
+    } else {
+#pragma unroll
+        for (int r = 0; r < M; ++r)   // flags: bit0 cell in mask, bit5 / bit6 the z- / z+ neighbour is in the mask
+            assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> 5) & 1u, (fb[r] >> 6) & 1u, HAS_DIR && db[r] != 0,
+                                         vin[r], vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r],
+                                         c[r], d[r]);
+        condense<M>(a, b, c, d, ip, k);
+    }
     // first-row data of the next segment of the same line
     const double gFn = __shfl_down(k.gF, 1, Lp), aFn = __shfl_down(k.aF, 1, Lp), cFn = __shfl_down(k.cF, 1, Lp);
     double ra, rb, rc, rd;
@@ -181,7 +204,8 @@ __global__ __launch_bounds__(256) void k_sweep_contig(
     double xL = __shfl_up(xS, 1, Lp);
     if (li == 0) xL = 0.0;
     double x[M];
-    back_solve<M>(a, c, d, ip, xL, xS, x);
+    if (fast) back_solve_uniform<M>(U, a0, kappa, d, xL, xS, x);
+    else back_solve<M>(a, c, d, ip, xL, xS, x);
 
     if (VEC) {
         if (active && r0 < n) {
@@ -218,52 +242,45 @@ struct LineGeom {
     int lbit;           // flags bit of the "previous row in mask" test (next row: lbit + 1)
 };
 
-template <int M, bool HAS_DIR, bool HAS_Q>
-__device__ __forceinline__ void load_segment_strided(
-    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
-    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    const LineGeom &g, long base, int r0, bool active, const SweepScal &s,
-    const double *__restrict__ xlo, const double *__restrict__ xhi, long line_id,
-    double (&a)[M], double (&b)[M], double (&c)[M], double (&d)[M])
-{
+template <int M>
+struct SegRaw {
     double vin[M], vco[M], vdv[M], vq[M];
     unsigned fb[M];
-#pragma unroll
-    for (int r = 0; r < M; ++r) {
-        const bool ok = active && (r0 + r) < g.n;
-        const long p = base + (long)(r0 + r) * g.stride;
-        fb[r] = ok ? flags[p] : 0u;
-        vin[r] = ok ? in[p] : 0.0;
-    }
     bool dirb[M];
+};
+
+template <int M, bool HAS_DIR, bool HAS_Q>
+__device__ __forceinline__ void load_segment_raw(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    const LineGeom &g, long base, int r0, bool active, const SweepScal &s, SegRaw<M> &R)
+{
 #pragma unroll
     for (int r = 0; r < M; ++r) {
         const bool ok = active && (r0 + r) < g.n;
         const long p = base + (long)(r0 + r) * g.stride;
-        const bool need = ok && (!s.sparse || axis_exposed(fb[r], g.lbit));
-        dirb[r] = false;
-        if (HAS_DIR) dirb[r] = ok && dmask[p] != 0;
-        vco[r] = need ? coeff[p] : 0.0;
-        if (HAS_Q) vq[r] = need ? qf[p] : 0.0;
-        if (HAS_DIR) vdv[r] = (ok && (!s.sparse || dirb[r])) ? dval[p] : 0.0;
+        R.fb[r] = ok ? flags[p] : 0u;
+        R.vin[r] = ok ? in[p] : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-        const bool dir = dirb[r];
-        assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> g.lbit) & 1u, (fb[r] >> (g.lbit + 1)) & 1u, dir, vin[r],
-                                     vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r], c[r], d[r]);
+        const bool ok = active && (r0 + r) < g.n;
+        const long p = base + (long)(r0 + r) * g.stride;
+        const bool need = ok && (!s.sparse || axis_exposed(R.fb[r], g.lbit));
+        R.dirb[r] = false;
+        if (HAS_DIR) R.dirb[r] = ok && dmask[p] != 0;
+        R.vco[r] = need ? coeff[p] : 0.0;
+        R.vq[r] = (HAS_Q && need) ? qf[p] : 0.0;
+        R.vdv[r] = (HAS_DIR && ok && (!s.sparse || R.dirb[r])) ? dval[p] : 0.0;
     }
-    // line ends: fold the coupling to the neighbouring GPU's row into the right-hand side
-    if (r0 == 0) {
-        if (xlo != nullptr && active) d[0] = __builtin_fma(-a[0], xlo[line_id], d[0]);
-        a[0] = 0.0;
-    }
-#pragma unroll
-    for (int r = 0; r < M; ++r)
-        if (r0 + r == g.n - 1) {
-            if (xhi != nullptr && active) d[r] = __builtin_fma(-c[r], xhi[line_id], d[r]);
-            c[r] = 0.0;
-        }
+}
+
+template <int M, bool HAS_DIR, bool HAS_Q>
+__device__ __forceinline__ void assemble_one(const SegRaw<M> &R, int r, int lbit, const SweepScal &s, double &a,
+                                             double &b, double &c, double &d)
+{
+    assemble_row<HAS_DIR, HAS_Q>(R.fb[r] & 1u, (R.fb[r] >> lbit) & 1u, (R.fb[r] >> (lbit + 1)) & 1u, R.dirb[r],
+                                 R.vin[r], R.vco[r], R.vdv[r], R.vq[r], s, a, b, c, d);
 }
 
 template <int M, bool HAS_DIR, bool HAS_Q>
@@ -271,7 +288,7 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ out, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
-    const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s)
+    const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s, UniC<M> U)
 {
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x;
@@ -284,13 +301,52 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
     const long base = to * g.outer_stride + kcol;
     const int r0 = sg * M;
 
+    SegRaw<M> R;
+    load_segment_raw<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R);
+    const long line_id = to * (long)g.n_inner + kcol;
+    bool lane_fast = s.sparse != 0;
+    {
+        const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
+        lane_fast = lane_fast && ((R.fb[0] & ROW0) == ROW0) && !R.dirb[0];
+#pragma unroll
+        for (int r = 1; r < M - 1; ++r) lane_fast = lane_fast && ((R.fb[r] & FULL) == FULL) && !R.dirb[r];
+    }
+    const bool fast = __all(lane_fast);
     double a[M], b[M], c[M], d[M];
-    load_segment_strided<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, xlo, xhi,
-                                            to * (long)g.n_inner + kcol, a, b, c, d);
-
     double ip[M - 1];
     Cond k;
-    condense<M>(a, b, c, d, ip, k);
+    double kappa = 0.0, a0 = 0.0;
+    if (fast) {
+        double b0, c0;
+        assemble_one<M, HAS_DIR, HAS_Q>(R, 0, g.lbit, s, a0, b0, c0, d[0]);
+        assemble_one<M, HAS_DIR, HAS_Q>(R, M - 1, g.lbit, s, a[M - 1], b[M - 1], c[M - 1], d[M - 1]);
+#pragma unroll
+        for (int r = 1; r < M - 1; ++r) d[r] = R.vin[r];
+        // line ends: fold the coupling to the neighbouring GPU's row into the right-hand side
+        if (r0 == 0) {
+            if (xlo != nullptr && active) d[0] = __builtin_fma(-a0, xlo[line_id], d[0]);
+            a0 = 0.0;
+        }
+        if (r0 + M - 1 == g.n - 1) {
+            if (xhi != nullptr && active) d[M - 1] = __builtin_fma(-c[M - 1], xhi[line_id], d[M - 1]);
+            c[M - 1] = 0.0;
+        }
+        condense_uniform<M>(U, a0, b0, d, k, kappa);
+    } else {
+#pragma unroll
+        for (int r = 0; r < M; ++r) assemble_one<M, HAS_DIR, HAS_Q>(R, r, g.lbit, s, a[r], b[r], c[r], d[r]);
+        if (r0 == 0) {
+            if (xlo != nullptr && active) d[0] = __builtin_fma(-a[0], xlo[line_id], d[0]);
+            a[0] = 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < M; ++r)
+            if (r0 + r == g.n - 1) {
+                if (xhi != nullptr && active) d[r] = __builtin_fma(-c[r], xhi[line_id], d[r]);
+                c[r] = 0.0;
+            }
+        condense<M>(a, b, c, d, ip, k);
+    }
 
     // LDS: 8 arrays [LINES][Lp + 1] (one padding column: conflict-free for both access directions)
     const int ld = Lp + 1;
@@ -325,7 +381,8 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
     const double xS = sXS[kk * ld + sg];
     const double xL = (sg > 0) ? sXS[kk * ld + sg - 1] : 0.0;
     double x[M];
-    back_solve<M>(a, c, d, ip, xL, xS, x);
+    if (fast) back_solve_uniform<M>(U, a0, kappa, d, xL, xS, x);
+    else back_solve<M>(a, c, d, ip, xL, xS, x);
 #pragma unroll
     for (int r = 0; r < M; ++r)
         if (active && (r0 + r) < g.n) out[base + (long)(r0 + r) * g.stride] = x[r];
@@ -802,10 +859,10 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
     const bool vec = aligned && (n % M == 0);
     if (vec)
         hipLaunchKernelGGL((k_sweep_contig<M, true, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
-                           dmask, dval, qf, out, L, Lp, s);
+                           dmask, dval, qf, out, L, Lp, s, make_unic<M>(s.tg));
     else
         hipLaunchKernelGGL((k_sweep_contig<M, false, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
-                           dmask, dval, qf, out, L, Lp, s);
+                           dmask, dval, qf, out, L, Lp, s, make_unic<M>(s.tg));
 }
 
 static void strided_tiling(int M, const LineGeom &g, int &Lp, int &lines, int &tiles_inner, long &ntiles, size_t &lds)
@@ -828,7 +885,7 @@ static void launch_strided(const double *in, const uint8_t *flags, const double 
     size_t lds;
     strided_tiling(M, g, Lp, lines, tiles_inner, ntiles, lds);
     hipLaunchKernelGGL((k_sweep_strided<M, HAS_DIR, HAS_Q>), dim3((unsigned)ntiles), dim3(lines * Lp), lds, st, in,
-                       flags, coeff, dmask, dval, qf, out, g, Lp, lines, tiles_inner, ntiles, xlo, xhi, s);
+                       flags, coeff, dmask, dval, qf, out, g, Lp, lines, tiles_inner, ntiles, xlo, xhi, s, make_unic<M>(s.tg));
 }
 
 template <int M, bool HAS_DIR, bool HAS_Q>

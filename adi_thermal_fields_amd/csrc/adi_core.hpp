@@ -130,6 +130,93 @@ __device__ __forceinline__ void back_solve(const double (&a)[M], const double (&
 }
 
 
+// ---- uniform-interior fast path -----------------------------------------------------------------------
+// Inside a solid region every row of a segment is a = c = s (= -theta*gamma), b = bu (= 1 + 2*theta*gamma):
+// the M-1 interior rows form the constant matrix Uint = tridiag(s, bu, s), whose inverse column
+// p = Uint^-1 e_0 and Thomas factors are computed ONCE on the host and passed as kernel arguments
+// (scalar registers).  A segment whose first row differs only in its diagonal / left coupling (line start,
+// exposed cell with a Robin coefficient) is Uint + delta e0 e0^T and is handled branch-free by
+// Sherman-Morrison:  A^-1 r = P r - kappa (p.r) p,  kappa = delta / (1 + delta p_0).
+// Replaces 2*(M-1) reciprocal chains by two dot products with constants.
+template <int M>
+struct UniC {
+    double s, bu;
+    double p[M - 1];    // first column of Uint^-1 (the last column is p reversed: Uint is persymmetric)
+    double w[M - 1];    // Thomas multipliers  w[r] = s * ip[r-1]   (w[0] unused)
+    double ip[M - 1];   // inverse pivots of the uniform Thomas factorisation
+};
+
+template <int M>
+__device__ __forceinline__ void condense_uniform(const UniC<M> &U, double a0, double b0, const double (&d)[M],
+                                                 Cond &k, double &kappa)
+{
+    constexpr int MI = M - 1;
+    double guF = 0.0, guL = 0.0;
+#pragma unroll
+    for (int r = 0; r < MI; ++r) {
+        guF = __builtin_fma(U.p[r], d[r], guF);
+        guL = __builtin_fma(U.p[MI - 1 - r], d[r], guL);
+    }
+    const double delta = b0 - U.bu;
+    kappa = delta * frcp(__builtin_fma(delta, U.p[0], 1.0));
+    const double f1 = __builtin_fma(-kappa, U.p[0], 1.0);
+    const double pl = U.p[MI - 1];
+    const double kpl = kappa * pl;
+    k.gF = guF * f1;
+    k.gL = __builtin_fma(-kpl, guF, guL);
+    k.aF = a0 * (U.p[0] * f1);
+    k.aL = a0 * (pl * f1);
+    k.cF = U.s * __builtin_fma(-kpl, U.p[0], pl);
+    k.cL = U.s * __builtin_fma(-kpl, pl, U.p[0]);
+}
+
+template <int M>
+__device__ __forceinline__ void back_solve_uniform(const UniC<M> &U, double a0, double kappa, const double (&d)[M],
+                                                   double xL, double xS, double (&x)[M])
+{
+    constexpr int MI = M - 1;
+    double y[MI];
+    y[0] = __builtin_fma(-a0, xL, d[0]);
+#pragma unroll
+    for (int r = 1; r < MI; ++r) y[r] = __builtin_fma(-U.w[r], y[r - 1], d[r]);
+    y[MI - 1] = __builtin_fma(-U.s, xS, y[MI - 1]);
+    x[MI - 1] = y[MI - 1] * U.ip[MI - 1];
+#pragma unroll
+    for (int r = MI - 2; r >= 0; --r) x[r] = __builtin_fma(-U.s, x[r + 1], y[r]) * U.ip[r];
+    const double t = kappa * x[0];
+#pragma unroll
+    for (int r = 0; r < MI; ++r) x[r] = __builtin_fma(-t, U.p[r], x[r]);
+    x[M - 1] = xS;
+}
+
+// host: constants for (s, bu)
+template <int M>
+inline UniC<M> make_unic(double tg)
+{
+    constexpr int MI = M - 1;
+    UniC<M> U;
+    const long double s = -(long double)tg, bu = 1.0L + 2.0L * (long double)tg;
+    U.s = (double)s;
+    U.bu = (double)bu;
+    long double ip[MI], w[MI], y[MI], x[MI];
+    ip[0] = 1.0L / bu;
+    w[0] = 0.0L;
+    for (int r = 1; r < MI; ++r) {
+        w[r] = s * ip[r - 1];
+        ip[r] = 1.0L / (bu - w[r] * s);
+    }
+    y[0] = 1.0L;   // Uint p = e_0
+    for (int r = 1; r < MI; ++r) y[r] = -w[r] * y[r - 1];
+    x[MI - 1] = y[MI - 1] * ip[MI - 1];
+    for (int r = MI - 2; r >= 0; --r) x[r] = (y[r] - s * x[r + 1]) * ip[r];
+    for (int r = 0; r < MI; ++r) {
+        U.p[r] = (double)x[r];
+        U.w[r] = (double)w[r];
+        U.ip[r] = (double)ip[r];
+    }
+    return U;
+}
+
 // ---- whole-block condensation and merging (distributed / two-level solves) ----------------------
 // condense_full: like condense(), but ALL M rows form the block (no separator): first/last unknown of
 // the block as affine functions of the value left of row 0 (xl) and right of row M-1 (xr):
