@@ -130,18 +130,29 @@ struct Lay {
     long sx;   // plane stride in elements (>= ny*nz); row stride is nz
 };
 
+// Work queue shared by the FAST and the GENERAL kernel of one sweep: q[0] = number of queued units,
+// q[1..] = unit ids.  A FAST kernel that meets a unit it cannot take (a wave / tile touching the surface of
+// the solid in a way the uniform model does not cover) appends the unit and leaves it to the GENERAL kernel
+// launched right behind it on the same stream, which reads every array of the pack.
+__device__ __forceinline__ void enqueue_unit(unsigned *queue, unsigned unit)
+{
+    const unsigned idx = atomicAdd(&queue[0], 1u);
+    queue[1 + idx] = unit;
+}
+
+// GENERAL body for one wave-unit (unit = index of a group of 64/Lp consecutive lines)
 template <int M, bool VEC, bool HAS_DIR, bool HAS_Q>
-__global__ __launch_bounds__(256) void k_sweep_contig(
+__device__ __forceinline__ void contig_unit_general(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    double *__restrict__ out, Lay L, int Lp, SweepScal s, UniC<M> U)
+    double *__restrict__ out, const Lay &L, int Lp, const SweepScal &s, long unit)
 {
     const int n = L.nz;
     const long nlines = (long)L.nx * L.ny;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int lw = 64 / Lp;  // lines per wave
     const int li = lane & (Lp - 1);
-    const long line = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * lw + (lane / Lp);
+    const long line = unit * lw + (lane / Lp);
     const bool active = line < nlines;
     const int r0 = li * M;
     const long pi = line / L.ny;
@@ -163,39 +174,14 @@ __global__ __launch_bounds__(256) void k_sweep_contig(
         if (HAS_Q) load_rows_contig<M, VEC>(qf, base, r0, n, active && need, vq);
         if (HAS_DIR) load_rows_contig<M, VEC>(dval, base, r0, n, active && needd, vdv);
     }
-
-    // uniform-interior fast path (wave-uniform decision): rows 1..M-2 have both z-neighbours in the mask and
-    // are not Dirichlet; row 0 may start a line or carry a Robin coefficient; the separator row is general
-    bool lane_fast = s.sparse != 0;
-    {
-        const unsigned FULL = 1u | (3u << 5), ROW0 = 1u | (1u << 6);
-        lane_fast = lane_fast && ((fb[0] & ROW0) == ROW0) && !(HAS_DIR && db[0] != 0);
-#pragma unroll
-        for (int r = 1; r < M - 1; ++r) lane_fast = lane_fast && ((fb[r] & FULL) == FULL) && !(HAS_DIR && db[r] != 0);
-    }
-    const bool fast = __all(lane_fast);
     double a[M], b[M], c[M], d[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r)   // flags: bit0 cell in mask, bit5 / bit6 the z- / z+ neighbour is in the mask
+        assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> 5) & 1u, (fb[r] >> 6) & 1u, HAS_DIR && db[r] != 0, vin[r],
+                                     vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r], c[r], d[r]);
     double ip[M - 1];
     Cond k;
-    double kappa = 0.0, a0 = 0.0;
-    if (fast) {
-        double b0, c0;
-        assemble_row<HAS_DIR, HAS_Q>(fb[0] & 1u, (fb[0] >> 5) & 1u, (fb[0] >> 6) & 1u, false, vin[0], vco[0], 0.0,
-                                     HAS_Q ? vq[0] : 0.0, s, a0, b0, c0, d[0]);
-        assemble_row<HAS_DIR, HAS_Q>(fb[M - 1] & 1u, (fb[M - 1] >> 5) & 1u, (fb[M - 1] >> 6) & 1u,
-                                     HAS_DIR && db[M - 1] != 0, vin[M - 1], vco[M - 1], HAS_DIR ? vdv[M - 1] : 0.0,
-                                     HAS_Q ? vq[M - 1] : 0.0, s, a[M - 1], b[M - 1], c[M - 1], d[M - 1]);
-#pragma unroll
-        for (int r = 1; r < M - 1; ++r) d[r] = vin[r];   // regular rows: no coefficient, no flux -> rhs = in
-        condense_uniform<M>(U, a0, b0, d, k, kappa);
-    } else {
-#pragma unroll
-        for (int r = 0; r < M; ++r)   // flags: bit0 cell in mask, bit5 / bit6 the z- / z+ neighbour is in the mask
-            assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> 5) & 1u, (fb[r] >> 6) & 1u, HAS_DIR && db[r] != 0,
-                                         vin[r], vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r],
-                                         c[r], d[r]);
-        condense<M>(a, b, c, d, ip, k);
-    }
+    condense<M>(a, b, c, d, ip, k);
     // first-row data of the next segment of the same line
     const double gFn = __shfl_down(k.gF, 1, Lp), aFn = __shfl_down(k.aF, 1, Lp), cFn = __shfl_down(k.cF, 1, Lp);
     double ra, rb, rc, rd;
@@ -204,9 +190,7 @@ __global__ __launch_bounds__(256) void k_sweep_contig(
     double xL = __shfl_up(xS, 1, Lp);
     if (li == 0) xL = 0.0;
     double x[M];
-    if (fast) back_solve_uniform<M>(U, a0, kappa, d, xL, xS, x);
-    else back_solve<M>(a, c, d, ip, xL, xS, x);
-
+    back_solve<M>(a, c, d, ip, xL, xS, x);
     if (VEC) {
         if (active && r0 < n) {
             double2 *q = reinterpret_cast<double2 *>(out + base);
@@ -217,6 +201,97 @@ __global__ __launch_bounds__(256) void k_sweep_contig(
 #pragma unroll
         for (int r = 0; r < M; ++r)
             if (active && r0 + r < n) out[base + r] = x[r];
+    }
+}
+
+// GENERAL kernel: every unit (queue == nullptr) or the units a FAST kernel queued
+template <int M, bool VEC, bool HAS_DIR, bool HAS_Q>
+__global__ __launch_bounds__(256) void k_sweep_contig(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ out, Lay L, int Lp, SweepScal s, long nunits, const unsigned *__restrict__ queue)
+{
+    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    if (queue == nullptr) {
+        const long unit = (long)blockIdx.x * wpb + wave;
+        if (unit < nunits)
+            contig_unit_general<M, VEC, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, Lp, s, unit);
+    } else {
+        const long cnt = queue[0];
+        for (long i = (long)blockIdx.x * wpb + wave; i < cnt; i += (long)gridDim.x * wpb)
+            contig_unit_general<M, VEC, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, Lp, s, queue[1 + i]);
+    }
+}
+
+// FAST kernel (sparse packs only): waves whose lanes all hold uniform-interior segments (rows 1..M-2 have both
+// z-neighbours in the mask and are not Dirichlet; row 0 may start a line / carry a Robin coefficient; the
+// separator row is general).  Such a wave needs no reciprocal chains (condense_uniform) and ~50 VGPRs, so
+// 8 waves per SIMD keep HBM busy.  Other waves are queued for the GENERAL kernel.
+template <int M, bool VEC, bool HAS_DIR, bool HAS_Q>
+__global__ __launch_bounds__(256) void k_sweep_contig_fast(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ out, Lay L, int Lp, SweepScal s, long nunits, unsigned *__restrict__ queue, UniC<M> U)
+{
+    const int n = L.nz;
+    const long nlines = (long)L.nx * L.ny;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long unit = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (unit >= nunits) return;
+    const int lw = 64 / Lp;
+    const int li = lane & (Lp - 1);
+    const long line = unit * lw + (lane / Lp);
+    const bool active = line < nlines;
+    const int r0 = li * M;
+    const long pi = line / L.ny;
+    const long base = pi * L.sx + (line - pi * L.ny) * (long)n + r0;
+
+    double d[M];
+    unsigned fb[M], db[M];
+    load_bytes_contig<M, VEC>(flags, base, r0, n, active, fb);
+    if (HAS_DIR) load_bytes_contig<M, VEC>(dmask, base, r0, n, active, db);
+    load_rows_contig<M, VEC>(in, base, r0, n, active, d);
+    bool lane_fast = true;
+    {
+        const unsigned FULL = 1u | (3u << 5), ROW0 = 1u | (1u << 6);
+        lane_fast = ((fb[0] & ROW0) == ROW0) && !(HAS_DIR && db[0] != 0);
+#pragma unroll
+        for (int r = 1; r < M - 1; ++r) lane_fast = lane_fast && ((fb[r] & FULL) == FULL) && !(HAS_DIR && db[r] != 0);
+    }
+    if (!__all(lane_fast)) {
+        if (lane == 0) enqueue_unit(queue, (unsigned)unit);
+        return;
+    }
+    // row 0 and the separator row are general rows; only they can carry a coefficient / flux / Dirichlet value
+    const bool e0 = axis_exposed(fb[0], 5), eS = axis_exposed(fb[M - 1], 5);
+    const double co0 = e0 ? coeff[base] : 0.0, coS = eS ? coeff[base + M - 1] : 0.0;
+    double q0 = 0.0, qS = 0.0, dvS = 0.0;
+    if (HAS_Q) { q0 = e0 ? qf[base] : 0.0; qS = eS ? qf[base + M - 1] : 0.0; }
+    const bool dirS = HAS_DIR && db[M - 1] != 0;
+    if (HAS_DIR) dvS = dirS ? dval[base + M - 1] : 0.0;
+    double a0, b0, c0, aS, bS, cS;
+    assemble_row<HAS_DIR, HAS_Q>(fb[0] & 1u, (fb[0] >> 5) & 1u, (fb[0] >> 6) & 1u, false, d[0], co0, 0.0, q0, s, a0,
+                                 b0, c0, d[0]);
+    assemble_row<HAS_DIR, HAS_Q>(fb[M - 1] & 1u, (fb[M - 1] >> 5) & 1u, (fb[M - 1] >> 6) & 1u, dirS, d[M - 1], coS,
+                                 dvS, qS, s, aS, bS, cS, d[M - 1]);
+    Cond k;
+    double kappa;
+    condense_uniform<M>(U, a0, b0, d, k, kappa);
+    const double gFn = __shfl_down(k.gF, 1, Lp), aFn = __shfl_down(k.aF, 1, Lp), cFn = __shfl_down(k.cF, 1, Lp);
+    double ra, rb, rc, rd;
+    reduced_row(aS, bS, cS, d[M - 1], k, gFn, aFn, cFn, ra, rb, rc, rd);
+    const double xS = pcr_solve(ra, rb, rc, rd, li, Lp);
+    double xL = __shfl_up(xS, 1, Lp);
+    if (li == 0) xL = 0.0;
+    double x[M];
+    back_solve_uniform<M>(U, a0, kappa, d, xL, xS, x);
+    if (VEC) {
+        double2 *q = reinterpret_cast<double2 *>(out + base);
+#pragma unroll
+        for (int i = 0; i < M / 2; ++i) q[i] = make_double2(x[2 * i], x[2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < M; ++r) out[base + r] = x[r];
     }
 }
 
@@ -283,12 +358,121 @@ __device__ __forceinline__ void assemble_one(const SegRaw<M> &R, int r, int lbit
                                  R.vin[r], R.vco[r], R.vdv[r], R.vq[r], s, a, b, c, d);
 }
 
+// separator system of a tile through LDS: line-major regrouping, in-wave PCR, separator values back
+__device__ __forceinline__ void tile_separators(double *sm, int tid, int kk, int sg, int Lp, int LINES, double aS,
+                                                double bS, double cS, double dS, const Cond &k, double &xL,
+                                                double &xS)
+{
+    // LDS: 8 arrays [LINES][Lp + 1] (one padding column: conflict-free for both access directions)
+    const int ld = Lp + 1;
+    const int plane = LINES * ld;
+    double *sX1 = sm, *sX2 = sm + plane, *sCS = sm + 2 * plane, *sX4 = sm + 3 * plane;
+    double *sGF = sm + 4 * plane, *sAF = sm + 5 * plane, *sCF = sm + 6 * plane, *sXS = sm + 7 * plane;
+    {
+        const int w = kk * ld + sg;
+        sX1[w] = -aS * k.aL;                          // ra
+        sX2[w] = __builtin_fma(-aS, k.cL, bS);        // rb without the next-segment term
+        sCS[w] = cS;
+        sX4[w] = __builtin_fma(-aS, k.gL, dS);        // rd without the next-segment term
+        sGF[w] = k.gF;
+        sAF[w] = k.aF;
+        sCF[w] = k.cF;
+    }
+    __syncthreads();
+    {
+        const int pl = tid / Lp, ps = tid - pl * Lp;  // line-major regrouping: Lp consecutive lanes = one line
+        const int w = pl * ld + ps;
+        const double c2 = sCS[w];
+        const bool hasn = ps < Lp - 1;
+        const double gFn = hasn ? sGF[w + 1] : 0.0, aFn = hasn ? sAF[w + 1] : 0.0, cFn = hasn ? sCF[w + 1] : 0.0;
+        const double ra = sX1[w];
+        const double rb = __builtin_fma(-c2, aFn, sX2[w]);
+        const double rc = -c2 * cFn;
+        const double rd = __builtin_fma(-c2, gFn, sX4[w]);
+        sXS[w] = pcr_solve(ra, rb, rc, rd, ps, Lp);
+    }
+    __syncthreads();
+    xS = sXS[kk * ld + sg];
+    xL = (sg > 0) ? sXS[kk * ld + sg - 1] : 0.0;
+}
+
+template <int M, bool HAS_DIR, bool HAS_Q>
+__device__ __forceinline__ void strided_tile_general(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ out, const LineGeom &g, int Lp, int LINES, int tiles_inner, long tile,
+    const double *__restrict__ xlo, const double *__restrict__ xhi, const SweepScal &s, double *sm)
+{
+    const int tid = threadIdx.x;
+    const long to = tile / tiles_inner;
+    const int ti = (int)(tile - to * tiles_inner);
+    const int kk = tid % LINES, sg = tid / LINES;
+    const int kcol = ti * LINES + kk;
+    const bool active = kcol < g.n_inner;
+    const long base = to * g.outer_stride + kcol;
+    const int r0 = sg * M;
+    const long line_id = to * (long)g.n_inner + kcol;
+
+    double a[M], b[M], c[M], d[M];
+    {
+        SegRaw<M> R;
+        load_segment_raw<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R);
+#pragma unroll
+        for (int r = 0; r < M; ++r) assemble_one<M, HAS_DIR, HAS_Q>(R, r, g.lbit, s, a[r], b[r], c[r], d[r]);
+    }
+    // line ends: fold the coupling to the neighbouring GPU's row into the right-hand side
+    if (r0 == 0) {
+        if (xlo != nullptr && active) d[0] = __builtin_fma(-a[0], xlo[line_id], d[0]);
+        a[0] = 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+        if (r0 + r == g.n - 1) {
+            if (xhi != nullptr && active) d[r] = __builtin_fma(-c[r], xhi[line_id], d[r]);
+            c[r] = 0.0;
+        }
+    double ip[M - 1];
+    Cond k;
+    condense<M>(a, b, c, d, ip, k);
+    double xL, xS;
+    tile_separators(sm, tid, kk, sg, Lp, LINES, a[M - 1], b[M - 1], c[M - 1], d[M - 1], k, xL, xS);
+    double x[M];
+    back_solve<M>(a, c, d, ip, xL, xS, x);
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+        if (active && (r0 + r) < g.n) out[base + (long)(r0 + r) * g.stride] = x[r];
+}
+
+// GENERAL kernel: every tile (queue == nullptr) or the tiles a FAST kernel queued
 template <int M, bool HAS_DIR, bool HAS_Q>
 __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ out, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
-    const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s, UniC<M> U)
+    const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s, const unsigned *__restrict__ queue)
+{
+    extern __shared__ __align__(16) double sm[];
+    if (queue == nullptr) {
+        strided_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, Lp, LINES, tiles_inner,
+                                                xcd_chunk_tile(blockIdx.x, ntiles), xlo, xhi, s, sm);
+    } else {
+        const long cnt = queue[0];
+        for (long i = blockIdx.x; i < cnt; i += gridDim.x) {
+            strided_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, Lp, LINES, tiles_inner,
+                                                    queue[1 + i], xlo, xhi, s, sm);
+            __syncthreads();   // the LDS arrays are reused by the next tile
+        }
+    }
+}
+
+// FAST kernel (sparse packs): tiles whose every segment is uniform-interior (see k_sweep_contig_fast)
+template <int M, bool HAS_DIR, bool HAS_Q>
+__global__ __launch_bounds__(512) void k_sweep_strided_fast(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ out, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
+    const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s, unsigned *__restrict__ queue,
+    UniC<M> U)
 {
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x;
@@ -300,92 +484,61 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
     const bool active = kcol < g.n_inner;
     const long base = to * g.outer_stride + kcol;
     const int r0 = sg * M;
-
-    SegRaw<M> R;
-    load_segment_raw<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R);
     const long line_id = to * (long)g.n_inner + kcol;
-    bool lane_fast = s.sparse != 0;
-    {
-        const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
-        lane_fast = lane_fast && ((R.fb[0] & ROW0) == ROW0) && !R.dirb[0];
-#pragma unroll
-        for (int r = 1; r < M - 1; ++r) lane_fast = lane_fast && ((R.fb[r] & FULL) == FULL) && !R.dirb[r];
-    }
-    const bool fast = __all(lane_fast);
-    double a[M], b[M], c[M], d[M];
-    double ip[M - 1];
-    Cond k;
-    double kappa = 0.0, a0 = 0.0;
-    if (fast) {
-        double b0, c0;
-        assemble_one<M, HAS_DIR, HAS_Q>(R, 0, g.lbit, s, a0, b0, c0, d[0]);
-        assemble_one<M, HAS_DIR, HAS_Q>(R, M - 1, g.lbit, s, a[M - 1], b[M - 1], c[M - 1], d[M - 1]);
-#pragma unroll
-        for (int r = 1; r < M - 1; ++r) d[r] = R.vin[r];
-        // line ends: fold the coupling to the neighbouring GPU's row into the right-hand side
-        if (r0 == 0) {
-            if (xlo != nullptr && active) d[0] = __builtin_fma(-a0, xlo[line_id], d[0]);
-            a0 = 0.0;
-        }
-        if (r0 + M - 1 == g.n - 1) {
-            if (xhi != nullptr && active) d[M - 1] = __builtin_fma(-c[M - 1], xhi[line_id], d[M - 1]);
-            c[M - 1] = 0.0;
-        }
-        condense_uniform<M>(U, a0, b0, d, k, kappa);
-    } else {
-#pragma unroll
-        for (int r = 0; r < M; ++r) assemble_one<M, HAS_DIR, HAS_Q>(R, r, g.lbit, s, a[r], b[r], c[r], d[r]);
-        if (r0 == 0) {
-            if (xlo != nullptr && active) d[0] = __builtin_fma(-a[0], xlo[line_id], d[0]);
-            a[0] = 0.0;
-        }
-#pragma unroll
-        for (int r = 0; r < M; ++r)
-            if (r0 + r == g.n - 1) {
-                if (xhi != nullptr && active) d[r] = __builtin_fma(-c[r], xhi[line_id], d[r]);
-                c[r] = 0.0;
-            }
-        condense<M>(a, b, c, d, ip, k);
-    }
 
-    // LDS: 8 arrays [LINES][Lp + 1] (one padding column: conflict-free for both access directions)
-    const int ld = Lp + 1;
-    const int plane = LINES * ld;
-    double *sX1 = sm, *sX2 = sm + plane, *sCS = sm + 2 * plane, *sX4 = sm + 3 * plane;
-    double *sGF = sm + 4 * plane, *sAF = sm + 5 * plane, *sCF = sm + 6 * plane, *sXS = sm + 7 * plane;
-    {
-        const int w = kk * ld + sg;
-        const double aS = a[M - 1];
-        sX1[w] = -aS * k.aL;                                  // ra
-        sX2[w] = __builtin_fma(-aS, k.cL, b[M - 1]);          // rb without the next-segment term
-        sCS[w] = c[M - 1];
-        sX4[w] = __builtin_fma(-aS, k.gL, d[M - 1]);          // rd without the next-segment term
-        sGF[w] = k.gF;
-        sAF[w] = k.aF;
-        sCF[w] = k.cF;
-    }
-    __syncthreads();
-    {
-        const int pl = tid / Lp, ps = tid - pl * Lp;  // line-major regrouping: Lp consecutive lanes = one line
-        const int w = pl * ld + ps;
-        const double cS = sCS[w];
-        const bool hasn = ps < Lp - 1;
-        const double gFn = hasn ? sGF[w + 1] : 0.0, aFn = hasn ? sAF[w + 1] : 0.0, cFn = hasn ? sCF[w + 1] : 0.0;
-        const double ra = sX1[w];
-        const double rb = __builtin_fma(-cS, aFn, sX2[w]);
-        const double rc = -cS * cFn;
-        const double rd = __builtin_fma(-cS, gFn, sX4[w]);
-        sXS[w] = pcr_solve(ra, rb, rc, rd, ps, Lp);
-    }
-    __syncthreads();
-    const double xS = sXS[kk * ld + sg];
-    const double xL = (sg > 0) ? sXS[kk * ld + sg - 1] : 0.0;
-    double x[M];
-    if (fast) back_solve_uniform<M>(U, a0, kappa, d, xL, xS, x);
-    else back_solve<M>(a, c, d, ip, xL, xS, x);
+    double d[M];
+    unsigned fb[M];
+    bool lane_fast = active && (r0 + M <= g.n);
+    const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
 #pragma unroll
-    for (int r = 0; r < M; ++r)
-        if (active && (r0 + r) < g.n) out[base + (long)(r0 + r) * g.stride] = x[r];
+    for (int r = 0; r < M; ++r) {
+        const bool ok = active && (r0 + r) < g.n;
+        const long p = base + (long)(r0 + r) * g.stride;
+        fb[r] = ok ? flags[p] : 0u;
+        d[r] = ok ? in[p] : 0.0;
+    }
+    bool dirS = false;
+    if (HAS_DIR) {
+#pragma unroll
+        for (int r = 0; r < M - 1; ++r)
+            lane_fast = lane_fast && (dmask[base + (long)(r0 + r) * g.stride] == 0 || !(active && (r0 + r) < g.n));
+        dirS = active && (r0 + M - 1) < g.n && dmask[base + (long)(r0 + M - 1) * g.stride] != 0;
+    }
+    lane_fast = lane_fast && ((fb[0] & ROW0) == ROW0);
+#pragma unroll
+    for (int r = 1; r < M - 1; ++r) lane_fast = lane_fast && ((fb[r] & FULL) == FULL);
+    if (!__syncthreads_and(lane_fast)) {
+        if (tid == 0) enqueue_unit(queue, (unsigned)tile);
+        return;
+    }
+    const long p0 = base + (long)r0 * g.stride, pS = base + (long)(r0 + M - 1) * g.stride;
+    const bool e0 = axis_exposed(fb[0], g.lbit), eS = axis_exposed(fb[M - 1], g.lbit);
+    const double co0 = e0 ? coeff[p0] : 0.0, coS = eS ? coeff[pS] : 0.0;
+    double q0 = 0.0, qS = 0.0, dvS = 0.0;
+    if (HAS_Q) { q0 = e0 ? qf[p0] : 0.0; qS = eS ? qf[pS] : 0.0; }
+    if (HAS_DIR) dvS = dirS ? dval[pS] : 0.0;
+    double a0, b0, c0, aS, bS, cS;
+    assemble_row<HAS_DIR, HAS_Q>(fb[0] & 1u, (fb[0] >> g.lbit) & 1u, (fb[0] >> (g.lbit + 1)) & 1u, false, d[0], co0, 0.0,
+                                 q0, s, a0, b0, c0, d[0]);
+    assemble_row<HAS_DIR, HAS_Q>(fb[M - 1] & 1u, (fb[M - 1] >> g.lbit) & 1u, (fb[M - 1] >> (g.lbit + 1)) & 1u, dirS,
+                                 d[M - 1], coS, dvS, qS, s, aS, bS, cS, d[M - 1]);
+    if (r0 == 0) {
+        if (xlo != nullptr) d[0] = __builtin_fma(-a0, xlo[line_id], d[0]);
+        a0 = 0.0;
+    }
+    if (r0 + M == g.n) {
+        if (xhi != nullptr) d[M - 1] = __builtin_fma(-cS, xhi[line_id], d[M - 1]);
+        cS = 0.0;
+    }
+    Cond k;
+    double kappa;
+    condense_uniform<M>(U, a0, b0, d, k, kappa);
+    double xL, xS;
+    tile_separators(sm, tid, kk, sg, Lp, LINES, aS, bS, cS, d[M - 1], k, xL, xS);
+    double x[M];
+    back_solve_uniform<M>(U, a0, kappa, d, xL, xS, x);
+#pragma unroll
+    for (int r = 0; r < M; ++r) out[base + (long)(r0 + r) * g.stride] = x[r];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -843,26 +996,48 @@ static LineGeom line_geom(int axis, const Lay &L, long *inner_stride)
     return g;
 }
 
+// sparse packs + a workspace for the unit queue -> FAST kernel first, GENERAL kernel on what it queued
+static bool use_fast(const SweepScal &s, void *work, size_t work_bytes, long nunits)
+{
+    static int off = -1;
+    if (off < 0) off = getenv("ADI_NO_FAST") ? 1 : 0;
+    return !off && s.sparse && work != nullptr && work_bytes >= (size_t)(nunits + 1) * sizeof(unsigned);
+}
+
 template <int M, bool HAS_DIR, bool HAS_Q>
 static void launch_contig(const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
                           const double *dval, const double *qf, double *out, const Lay &L, SweepScal s,
-                          hipStream_t st)
+                          void *work, size_t work_bytes, hipStream_t st)
 {
     const int n = L.nz;
     const long nlines = (long)L.nx * L.ny;
     const int Lp = next_pow2((n + M - 1) / M);
     const int lw = 64 / Lp;
-    const long waves = (nlines + lw - 1) / lw;
-    const unsigned grid = (unsigned)((waves + 3) / 4);
+    const long nunits = (nlines + lw - 1) / lw;
+    const unsigned grid = (unsigned)((nunits + 3) / 4);
     const bool aligned = (((uintptr_t)in | (uintptr_t)coeff | (uintptr_t)out | (uintptr_t)dval | (uintptr_t)qf) & 15) == 0 &&
                          (((uintptr_t)flags | (uintptr_t)dmask) & 7) == 0 && (L.sx % 8 == 0);
     const bool vec = aligned && (n % M == 0);
+    const bool fast = use_fast(s, work, work_bytes, nunits) && (n % M == 0);
+    unsigned *queue = fast ? (unsigned *)work : nullptr;
+    unsigned ggrid = grid;
+    if (fast) {
+        (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
+        const UniC<M> U = make_unic<M>(s.tg);
+        if (vec)
+            hipLaunchKernelGGL((k_sweep_contig_fast<M, true, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags,
+                               coeff, dmask, dval, qf, out, L, Lp, s, nunits, queue, U);
+        else
+            hipLaunchKernelGGL((k_sweep_contig_fast<M, false, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags,
+                               coeff, dmask, dval, qf, out, L, Lp, s, nunits, queue, U);
+        ggrid = grid < 2048u ? grid : 2048u;
+    }
     if (vec)
-        hipLaunchKernelGGL((k_sweep_contig<M, true, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
-                           dmask, dval, qf, out, L, Lp, s, make_unic<M>(s.tg));
+        hipLaunchKernelGGL((k_sweep_contig<M, true, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(256), 0, st, in, flags, coeff,
+                           dmask, dval, qf, out, L, Lp, s, nunits, queue);
     else
-        hipLaunchKernelGGL((k_sweep_contig<M, false, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
-                           dmask, dval, qf, out, L, Lp, s, make_unic<M>(s.tg));
+        hipLaunchKernelGGL((k_sweep_contig<M, false, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(256), 0, st, in, flags, coeff,
+                           dmask, dval, qf, out, L, Lp, s, nunits, queue);
 }
 
 static void strided_tiling(int M, const LineGeom &g, int &Lp, int &lines, int &tiles_inner, long &ntiles, size_t &lds)
@@ -878,14 +1053,25 @@ static void strided_tiling(int M, const LineGeom &g, int &Lp, int &lines, int &t
 template <int M, bool HAS_DIR, bool HAS_Q>
 static void launch_strided(const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
                            const double *dval, const double *qf, double *out, const LineGeom &g,
-                           const double *xlo, const double *xhi, SweepScal s, hipStream_t st)
+                           const double *xlo, const double *xhi, SweepScal s, void *work, size_t work_bytes,
+                           hipStream_t st)
 {
     int Lp, lines, tiles_inner;
     long ntiles;
     size_t lds;
     strided_tiling(M, g, Lp, lines, tiles_inner, ntiles, lds);
-    hipLaunchKernelGGL((k_sweep_strided<M, HAS_DIR, HAS_Q>), dim3((unsigned)ntiles), dim3(lines * Lp), lds, st, in,
-                       flags, coeff, dmask, dval, qf, out, g, Lp, lines, tiles_inner, ntiles, xlo, xhi, s, make_unic<M>(s.tg));
+    const bool fast = use_fast(s, work, work_bytes, ntiles) && (g.n % M == 0) && (lines * Lp <= 512);
+    unsigned *queue = fast ? (unsigned *)work : nullptr;
+    unsigned ggrid = (unsigned)ntiles;
+    if (fast) {
+        (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
+        hipLaunchKernelGGL((k_sweep_strided_fast<M, HAS_DIR, HAS_Q>), dim3((unsigned)ntiles), dim3(lines * Lp), lds, st,
+                           in, flags, coeff, dmask, dval, qf, out, g, Lp, lines, tiles_inner, ntiles, xlo, xhi, s, queue,
+                           make_unic<M>(s.tg));
+        ggrid = ntiles < 1024 ? (unsigned)ntiles : 1024u;
+    }
+    hipLaunchKernelGGL((k_sweep_strided<M, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(lines * Lp), lds, st, in, flags, coeff,
+                       dmask, dval, qf, out, g, Lp, lines, tiles_inner, ntiles, xlo, xhi, s, queue);
 }
 
 template <int M, bool HAS_DIR, bool HAS_Q>
@@ -921,17 +1107,17 @@ static int sweep_dispatch(int axis, const double *in, const uint8_t *flags, cons
     }
     if (axis == 2) {
         switch (contig_rows_per_lane(n)) {
-            case 2: launch_contig<2, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, st); break;
-            case 4: launch_contig<4, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, st); break;
-            case 8: launch_contig<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, st); break;
-            default: launch_contig<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, st); break;
+            case 2: launch_contig<2, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, work, work_bytes, st); break;
+            case 4: launch_contig<4, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, work, work_bytes, st); break;
+            case 8: launch_contig<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, work, work_bytes, st); break;
+            default: launch_contig<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, work, work_bytes, st); break;
         }
     } else {
         switch (strided_rows_per_thread(n)) {
-            case 2: launch_strided<2, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, st); break;
-            case 4: launch_strided<4, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, st); break;
-            case 8: launch_strided<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, st); break;
-            default: launch_strided<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, st); break;
+            case 2: launch_strided<2, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, work, work_bytes, st); break;
+            case 4: launch_strided<4, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, work, work_bytes, st); break;
+            case 8: launch_strided<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, work, work_bytes, st); break;
+            default: launch_strided<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, work, work_bytes, st); break;
         }
     }
     return ADI_OK;
@@ -1072,7 +1258,10 @@ int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, long plane_strid
     Lay L;
     if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
     const int nn[3] = {nx, ny, nz};
-    *bytes = nn[axis] > kMaxFastLine ? (size_t)2 * nx * L.sx * sizeof(double) : 0;
+    // long lines: c', d' scratch; otherwise the unit queue of the FAST/GENERAL kernel pair (one id per tile or
+    // line group; nx*ny*nz/8 + 1 ids is an upper bound for every tiling this library uses)
+    const size_t cells = (size_t)nx * ny * nz;
+    *bytes = nn[axis] > kMaxFastLine ? (size_t)2 * nx * L.sx * sizeof(double) : (cells / 8 + 64) * sizeof(unsigned);
     return ADI_OK;
 }
 

@@ -157,10 +157,22 @@ class HipEngine:
         return (axis, variant, h._p(t_in), h._p(flags), h._p(pack[0]), h._p(pack[1]), h._p(pack[2]), h._p(pack[3]),
                 Li.nx, Li.ny, Li.nz, Li.sx, 1, theta, gam, dt, float(Tinf))   # packs come from adi_build_coeffs: sparse ok
 
+    def _workspace(self, Li):
+        """unit queue of the FAST/GENERAL kernel pair (sized for the largest box seen)"""
+        need = 0
+        for ax in range(3):
+            b = ctypes.c_size_t(0)
+            self.check(self.lib.adi_sweep_workspace_bytes(ax, Li.nx, Li.ny, Li.nz, Li.sx, ctypes.byref(b)))
+            need = max(need, b.value)
+        if getattr(self, '_work', None) is None or self._work.numel() < need:
+            self._work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._work
+
     def sweep(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, xlo=None, xhi=None):
         h = self.hip
+        w = self._workspace(Li)
         self.check(self.lib.adi_sweep(*self._args(axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf),
-                                      h._p(t_out), h._p(xlo), h._p(xhi), None, 0, h._stream()))
+                                      h._p(t_out), h._p(xlo), h._p(xhi), h._p(w), w.numel(), h._stream()))
 
     def condense(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, cond):
         h = self.hip
