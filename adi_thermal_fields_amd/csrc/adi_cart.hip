@@ -251,6 +251,11 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     load_bytes_contig<M, VEC>(flags, base, r0, n, active, fb);
     if (HAS_DIR) load_bytes_contig<M, VEC>(dmask, base, r0, n, active, db);
     load_rows_contig<M, VEC>(in, base, r0, n, active, d);
+    // the two ends of a line are always exposed: fetch their coefficient / flux with the first batch of loads
+    const bool sp0 = active && li == 0, spS = active && (r0 + M == n);
+    const double co0s = sp0 ? coeff[base] : 0.0, coSs = spS ? coeff[base + M - 1] : 0.0;
+    double q0s = 0.0, qSs = 0.0;
+    if (HAS_Q) { q0s = sp0 ? qf[base] : 0.0; qSs = spS ? qf[base + M - 1] : 0.0; }
     bool lane_fast = true;
     {
         const unsigned FULL = 1u | (3u << 5), ROW0 = 1u | (1u << 6);
@@ -264,9 +269,9 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     }
     // row 0 and the separator row are general rows; only they can carry a coefficient / flux / Dirichlet value
     const bool e0 = axis_exposed(fb[0], 5), eS = axis_exposed(fb[M - 1], 5);
-    const double co0 = e0 ? coeff[base] : 0.0, coS = eS ? coeff[base + M - 1] : 0.0;
+    const double co0 = e0 ? (sp0 ? co0s : coeff[base]) : 0.0, coS = eS ? (spS ? coSs : coeff[base + M - 1]) : 0.0;
     double q0 = 0.0, qS = 0.0, dvS = 0.0;
-    if (HAS_Q) { q0 = e0 ? qf[base] : 0.0; qS = eS ? qf[base + M - 1] : 0.0; }
+    if (HAS_Q) { q0 = e0 ? (sp0 ? q0s : qf[base]) : 0.0; qS = eS ? (spS ? qSs : qf[base + M - 1]) : 0.0; }
     const bool dirS = HAS_DIR && db[M - 1] != 0;
     if (HAS_DIR) dvS = dirS ? dval[base + M - 1] : 0.0;
     double a0, b0, c0, aS, bS, cS;

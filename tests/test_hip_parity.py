@@ -118,3 +118,29 @@ def test_cyl_bad_kind(hipcyl):
     c['zbc'] = dict(kind_bot='bogus', kind_top='robin')
     with pytest.raises(ValueError):
         run_cyl_case(hipcyl, c)
+
+
+@pytest.mark.parametrize('shape', [(512, 6, 24), (6, 24, 512), (10, 512, 16), (256, 8, 256)])
+def test_long_lines_fast_and_general_units(hip, shape):
+    """lines of 256/512 rows (M = 4/8, 64 lanes per line): mostly solid, so the FAST kernels take most units, with
+    holes, a Dirichlet plane, a Neumann face and Robin everywhere forcing queued GENERAL units in the same sweep"""
+    from oracle import adi_oracle as orc
+    rng = np.random.default_rng(sum(shape))
+    mask = np.ones(shape, bool)
+    for _ in range(12):          # a few voids
+        i, j, k = (rng.integers(0, n) for n in shape)
+        mask[max(0, i - 3):i + 3, max(0, j - 1):j + 2, max(0, k - 3):k + 3] = False
+    dm = np.zeros(shape, bool); dm[:, 0, :] = mask[:, 0, :]
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,
+             T0=rng.uniform(20.0, 1200.0, shape), dir_mask=dm, dir_value=150.0,
+             neumann={'z+': 3e5, 'x-': rng.uniform(0, 2e5, shape)}, robin_h=400.0, Tinf=20.0, theta=0.5,
+             dt=250.0 * dx * dx / alpha, nsteps=2, births=None)
+    got = run_cart_case(hip, c)['T_final']
+    want = run_cart_case(orc, c)['T_final']
+    assert rel_linf(got, want) <= TOL, rel_linf(got, want)
+    c2 = dict(c, dir_mask=None, dir_value=None, neumann=None)      # lean variant
+    got = run_cart_case(hip, c2)['T_final']
+    want = run_cart_case(orc, c2)['T_final']
+    assert rel_linf(got, want) <= TOL, rel_linf(got, want)
