@@ -164,7 +164,7 @@ def main():
             if it >= 3:
                 ms.append(e0.elapsed_time(e1))
         m = float(np.mean(ms))
-        xs = dict(kernel='k_sweep_contig<8,vec,dir,q> (general pack)', ms=round(m, 4), bytes_per_cell=42,
+        xs = dict(kernel='k_sweep_contig<8,vec,dir,q> (general pack, every pack array read in full)', ms=round(m, 4), bytes_per_cell=42,
                   achieved_gbs=round(42 * N / (m * 1e-3) / 1e9, 1),
                   frac=round(42 * N / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
 
