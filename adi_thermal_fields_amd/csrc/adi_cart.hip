@@ -553,60 +553,11 @@ __global__ __launch_bounds__(512) void k_sweep_strided_fast(
 // the line to its neighbours:  x_first = gF - aF*xl - cF*xr,  x_last = gL - aL*xl - cL*xr.
 // Requires n % M == 0 (whole segments).  cond: [6][nlines] dense.
 // ------------------------------------------------------------------------------------------------
-template <int M, bool HAS_DIR, bool HAS_Q>
-__global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_condense_strided(
-    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
-    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    double *__restrict__ cond, long nlines, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
-    SweepScal s)
+// lane 0 of every line: ordered merge of the Lp block condensations -> six numbers per line
+__device__ __forceinline__ void tile_reduce_store(double *sm, int tid, int kk, int sg, int Lp, int LINES, const Cond &k,
+                                                  int nblk, long to, int ti, const LineGeom &g, long nlines,
+                                                  double *__restrict__ cond)
 {
-    extern __shared__ __align__(16) double sm[];
-    const int tid = threadIdx.x;
-    const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
-    const long to = tile / tiles_inner;
-    const int ti = (int)(tile - to * tiles_inner);
-    const int kk = tid % LINES, sg = tid / LINES;
-    const int kcol = ti * LINES + kk;
-    const bool active = kcol < g.n_inner;
-    const long base = to * g.outer_stride + kcol;
-    const int r0 = sg * M;
-
-    double a[M], b[M], c[M], d[M];
-    {
-        // same assembly as the solve pass, but the end couplings stay in a[0] / c[n-1] (they are the
-        // aF, aL / cF, cL of the slab)
-        double vin[M], vco[M], vdv[M], vq[M];
-        unsigned fb[M];
-#pragma unroll
-        for (int r = 0; r < M; ++r) {
-            const bool ok = active && (r0 + r) < g.n;
-            const long p = base + (long)(r0 + r) * g.stride;
-            fb[r] = ok ? flags[p] : 0u;
-            vin[r] = ok ? in[p] : 0.0;
-        }
-        bool dirb[M];
-#pragma unroll
-        for (int r = 0; r < M; ++r) {
-            const bool ok = active && (r0 + r) < g.n;
-            const long p = base + (long)(r0 + r) * g.stride;
-            const bool need = ok && (!s.sparse || axis_exposed(fb[r], g.lbit));
-            dirb[r] = false;
-            if (HAS_DIR) dirb[r] = ok && dmask[p] != 0;
-            vco[r] = need ? coeff[p] : 0.0;
-            if (HAS_Q) vq[r] = need ? qf[p] : 0.0;
-            if (HAS_DIR) vdv[r] = (ok && (!s.sparse || dirb[r])) ? dval[p] : 0.0;
-        }
-#pragma unroll
-        for (int r = 0; r < M; ++r) {
-            const bool dir = dirb[r];
-            assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> g.lbit) & 1u, (fb[r] >> (g.lbit + 1)) & 1u, dir,
-                                         vin[r], vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r],
-                                         c[r], d[r]);
-        }
-    }
-    Cond k;
-    condense_full<M>(a, b, c, d, k);
-
     const int ld = Lp + 1;
     const int plane = LINES * ld;
     {
@@ -620,13 +571,130 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_condense_strided(
     Cond q;
     q.gF = sm[w]; q.aF = sm[plane + w]; q.cF = sm[2 * plane + w];
     q.gL = sm[3 * plane + w]; q.aL = sm[4 * plane + w]; q.cL = sm[5 * plane + w];
-    q = reduce_cond(q, ps, Lp, g.n / M);
+    q = reduce_cond(q, ps, Lp, nblk);
     const int kc2 = ti * LINES + pl;
     if (ps == 0 && kc2 < g.n_inner) {
         const long id = to * (long)g.n_inner + kc2;
         cond[id] = q.gF; cond[nlines + id] = q.aF; cond[2 * nlines + id] = q.cF;
         cond[3 * nlines + id] = q.gL; cond[4 * nlines + id] = q.aL; cond[5 * nlines + id] = q.cL;
     }
+}
+
+template <int M, bool HAS_DIR, bool HAS_Q>
+__device__ __forceinline__ void condense_tile_general(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ cond, long nlines, const LineGeom &g, int Lp, int LINES, int tiles_inner, long tile,
+    const SweepScal &s, double *sm)
+{
+    const int tid = threadIdx.x;
+    const long to = tile / tiles_inner;
+    const int ti = (int)(tile - to * tiles_inner);
+    const int kk = tid % LINES, sg = tid / LINES;
+    const int kcol = ti * LINES + kk;
+    const bool active = kcol < g.n_inner;
+    const long base = to * g.outer_stride + kcol;
+    const int r0 = sg * M;
+    double a[M], b[M], c[M], d[M];
+    {
+        // same assembly as the solve pass, but the end couplings stay in a[0] / c[n-1] (they are the
+        // aF, aL / cF, cL of the slab)
+        SegRaw<M> R;
+        load_segment_raw<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R);
+#pragma unroll
+        for (int r = 0; r < M; ++r) assemble_one<M, HAS_DIR, HAS_Q>(R, r, g.lbit, s, a[r], b[r], c[r], d[r]);
+    }
+    Cond k;
+    condense_full<M>(a, b, c, d, k);
+    tile_reduce_store(sm, tid, kk, sg, Lp, LINES, k, g.n / M, to, ti, g, nlines, cond);
+}
+
+template <int M, bool HAS_DIR, bool HAS_Q>
+__global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_condense_strided(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ cond, long nlines, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
+    SweepScal s, const unsigned *__restrict__ queue)
+{
+    extern __shared__ __align__(16) double sm[];
+    if (queue == nullptr) {
+        condense_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, LINES,
+                                                 tiles_inner, xcd_chunk_tile(blockIdx.x, ntiles), s, sm);
+    } else {
+        const long cnt = queue[0];
+        for (long i = blockIdx.x; i < cnt; i += gridDim.x) {
+            condense_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, LINES,
+                                                     tiles_inner, queue[1 + i], s, sm);
+            __syncthreads();
+        }
+    }
+}
+
+// FAST pass A: uniform-interior segments (see k_sweep_strided_fast); the block of a thread = its M-1 uniform
+// interior rows merged with its general separator row.
+template <int M, bool HAS_DIR, bool HAS_Q>
+__global__ __launch_bounds__(512) void k_condense_strided_fast(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ cond, long nlines, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
+    SweepScal s, unsigned *__restrict__ queue, UniC<M> U)
+{
+    extern __shared__ __align__(16) double sm[];
+    const int tid = threadIdx.x;
+    const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
+    const long to = tile / tiles_inner;
+    const int ti = (int)(tile - to * tiles_inner);
+    const int kk = tid % LINES, sg = tid / LINES;
+    const int kcol = ti * LINES + kk;
+    const bool active = kcol < g.n_inner;
+    const long base = to * g.outer_stride + kcol;
+    const int r0 = sg * M;
+
+    double d[M];
+    unsigned fb[M];
+    bool lane_fast = active && (r0 + M <= g.n);
+    const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        const bool ok = active && (r0 + r) < g.n;
+        const long p = base + (long)(r0 + r) * g.stride;
+        fb[r] = ok ? flags[p] : 0u;
+        d[r] = ok ? in[p] : 0.0;
+    }
+    bool dirS = false;
+    if (HAS_DIR) {
+#pragma unroll
+        for (int r = 0; r < M - 1; ++r) lane_fast = lane_fast && (dmask[base + (long)(r0 + r) * g.stride] == 0);
+        dirS = active && (r0 + M - 1) < g.n && dmask[base + (long)(r0 + M - 1) * g.stride] != 0;
+    }
+    lane_fast = lane_fast && ((fb[0] & ROW0) == ROW0);
+#pragma unroll
+    for (int r = 1; r < M - 1; ++r) lane_fast = lane_fast && ((fb[r] & FULL) == FULL);
+    if (!__syncthreads_and(lane_fast)) {
+        if (tid == 0) enqueue_unit(queue, (unsigned)tile);
+        return;
+    }
+    const long p0 = base + (long)r0 * g.stride, pS = base + (long)(r0 + M - 1) * g.stride;
+    const bool e0 = axis_exposed(fb[0], g.lbit), eS = axis_exposed(fb[M - 1], g.lbit);
+    const double co0 = e0 ? coeff[p0] : 0.0, coS = eS ? coeff[pS] : 0.0;
+    double q0 = 0.0, qS = 0.0, dvS = 0.0;
+    if (HAS_Q) { q0 = e0 ? qf[p0] : 0.0; qS = eS ? qf[pS] : 0.0; }
+    if (HAS_DIR) dvS = dirS ? dval[pS] : 0.0;
+    double a0, b0, c0, aS, bS, cS;
+    assemble_row<HAS_DIR, HAS_Q>(fb[0] & 1u, (fb[0] >> g.lbit) & 1u, (fb[0] >> (g.lbit + 1)) & 1u, false, d[0], co0, 0.0,
+                                 q0, s, a0, b0, c0, d[0]);
+    assemble_row<HAS_DIR, HAS_Q>(fb[M - 1] & 1u, (fb[M - 1] >> g.lbit) & 1u, (fb[M - 1] >> (g.lbit + 1)) & 1u, dirS,
+                                 d[M - 1], coS, dvS, qS, s, aS, bS, cS, d[M - 1]);
+    Cond ki;
+    double kappa;
+    condense_uniform<M>(U, a0, b0, d, ki, kappa);
+    const double ib = frcp(bS);
+    Cond rowc;
+    rowc.gF = rowc.gL = d[M - 1] * ib;
+    rowc.aF = rowc.aL = aS * ib;
+    rowc.cF = rowc.cL = cS * ib;
+    const Cond k = merge_cond(ki, rowc);
+    tile_reduce_store(sm, tid, kk, sg, Lp, LINES, k, g.n / M, to, ti, g, nlines, cond);
 }
 
 // K5b: generic slab condensation, one thread per line, two serial recurrences (any n; reads rows twice).
@@ -1082,14 +1150,24 @@ static void launch_strided(const double *in, const uint8_t *flags, const double 
 template <int M, bool HAS_DIR, bool HAS_Q>
 static void launch_condense(const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
                             const double *dval, const double *qf, double *cond, long nlines, const LineGeom &g,
-                            SweepScal s, hipStream_t st)
+                            SweepScal s, void *work, size_t work_bytes, hipStream_t st)
 {
     int Lp, lines, tiles_inner;
     long ntiles;
     size_t lds;
     strided_tiling(M, g, Lp, lines, tiles_inner, ntiles, lds);
-    hipLaunchKernelGGL((k_condense_strided<M, HAS_DIR, HAS_Q>), dim3((unsigned)ntiles), dim3(lines * Lp), lds, st, in,
-                       flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, lines, tiles_inner, ntiles, s);
+    const bool fast = use_fast(s, work, work_bytes, ntiles) && (lines * Lp <= 512);
+    unsigned *queue = fast ? (unsigned *)work : nullptr;
+    unsigned ggrid = (unsigned)ntiles;
+    if (fast) {
+        (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
+        hipLaunchKernelGGL((k_condense_strided_fast<M, HAS_DIR, HAS_Q>), dim3((unsigned)ntiles), dim3(lines * Lp), lds,
+                           st, in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, lines, tiles_inner, ntiles, s,
+                           queue, make_unic<M>(s.tg));
+        ggrid = ntiles < 1024 ? (unsigned)ntiles : 1024u;
+    }
+    hipLaunchKernelGGL((k_condense_strided<M, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(lines * Lp), lds, st, in, flags,
+                       coeff, dmask, dval, qf, cond, nlines, g, Lp, lines, tiles_inner, ntiles, s, queue);
 }
 
 template <bool HAS_DIR, bool HAS_Q>
@@ -1131,7 +1209,7 @@ static int sweep_dispatch(int axis, const double *in, const uint8_t *flags, cons
 template <bool HAS_DIR, bool HAS_Q>
 static int condense_dispatch(int axis, const double *in, const uint8_t *flags, const double *coeff,
                              const uint8_t *dmask, const double *dval, const double *qf, const Lay &L, SweepScal s,
-                             double *cond, hipStream_t st)
+                             double *cond, void *work, size_t work_bytes, hipStream_t st)
 {
     long inner_stride;
     const LineGeom g = line_geom(axis, L, &inner_stride);
@@ -1144,10 +1222,10 @@ static int condense_dispatch(int axis, const double *in, const uint8_t *flags, c
             if (n % m == 0 && n / m <= 64) { M = m; break; }
     }
     switch (M) {
-        case 2: launch_condense<2, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, st); break;
-        case 4: launch_condense<4, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, st); break;
-        case 8: launch_condense<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, st); break;
-        case 16: launch_condense<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, st); break;
+        case 2: launch_condense<2, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, work, work_bytes, st); break;
+        case 4: launch_condense<4, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, work, work_bytes, st); break;
+        case 8: launch_condense<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, work, work_bytes, st); break;
+        case 16: launch_condense<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, work, work_bytes, st); break;
         default:
             hipLaunchKernelGGL((k_condense_generic<HAS_DIR, HAS_Q>), dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0,
                                st, in, flags, coeff, dmask, dval, qf, cond, nlines, g, inner_stride, s);
@@ -1311,7 +1389,7 @@ int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags,
 int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
                        const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny,
                        int nz, long plane_stride, int sparse, double theta, double gam, double dt, double Tinf,
-                       double *d_cond, void *stream)
+                       double *d_cond, void *d_work, size_t work_bytes, void *stream)
 {
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep_condense: bad axis %d", axis);
     bool has_dir, has_q;
@@ -1327,10 +1405,10 @@ int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t 
     s.Tinf = Tinf;
     s.sparse = sparse ? 1 : 0;
     hipStream_t st = as_stream(stream);
-    if (has_dir && has_q) condense_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, L, s, d_cond, st);
-    else if (has_q) condense_dispatch<false, true>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, d_qflux, L, s, d_cond, st);
-    else if (has_dir) condense_dispatch<true, false>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, nullptr, L, s, d_cond, st);
-    else condense_dispatch<false, false>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, nullptr, L, s, d_cond, st);
+    if (has_dir && has_q) condense_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, L, s, d_cond, d_work, work_bytes, st);
+    else if (has_q) condense_dispatch<false, true>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, d_qflux, L, s, d_cond, d_work, work_bytes, st);
+    else if (has_dir) condense_dispatch<true, false>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, nullptr, L, s, d_cond, d_work, work_bytes, st);
+    else condense_dispatch<false, false>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, nullptr, L, s, d_cond, d_work, work_bytes, st);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }

@@ -176,8 +176,9 @@ class HipEngine:
 
     def condense(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, cond):
         h = self.hip
+        w = self._workspace(Li)
         self.check(self.lib.adi_sweep_condense(*self._args(axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf),
-                                               h._p(cond), h._stream()))
+                                               h._p(cond), h._p(w), w.numel(), h._stream()))
 
     def interface(self, cond_all, world, rank, nlines, xlo, xhi):
         h = self.hip

@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 3
+#define ADI_ABI_VERSION 4
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -110,7 +110,9 @@ int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, 
  * sparse != 0 asserts the invariant of packs built by adi_build_coeffs -- coeff/qflux of this axis are zero
  * except on cells that lack an in-mask neighbour along the axis -- so the kernel loads them only there
  * (and dir_val only where dir_mask is set).  Pass 0 for hand-built packs.
- * d_work/work_bytes: scratch for lines longer than the in-register limit (adi_sweep_workspace_bytes).
+ * d_work/work_bytes (adi_sweep_workspace_bytes): c'/d' scratch for lines longer than the in-register limit,
+ * otherwise the unit queue that lets a sparse sweep run as a FAST kernel (solid interior) followed by the
+ * GENERAL kernel on the queued surface units; with NULL/0 the GENERAL kernel processes everything.
  */
 int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
               const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux,
@@ -129,7 +131,8 @@ int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, long plane_strid
 int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t *d_flags,
                        const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
                        const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse,
-                       double theta, double gam, double dt, double Tinf, double *d_cond, void *stream);
+                       double theta, double gam, double dt, double Tinf, double *d_cond,
+                       void *d_work, size_t work_bytes, void *stream);
 /* d_cond_all: [nranks][6][nlines], the all-gathered pass-A output ordered by slab.  Solves the reduced
  * interface system of every line and writes this rank's boundary values for pass B (adi_sweep). */
 int adi_interface_solve(const double *d_cond_all, int nranks, int rank, long nlines,
