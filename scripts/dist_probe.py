@@ -52,3 +52,37 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+def parts():
+    """time pass A / interface / pass B separately on the full slab (no chunking)"""
+    n = 512; world = 8
+    mat = adi.Material(7800.0, 490.0, 54.0)
+    alpha = mat.k / (mat.rho * mat.cp)
+    dx = 5e-4
+    prm = adi.Params(200.0 * dx * dx / alpha, 0.5)
+    st = dist_slab.SlabStepper(np.ones((n, n, n), bool), dx, mat, prm, 20.0, robin_h=500.0, comm=FakeComm(world, 3))
+    E = st.engine
+    A = dist_slab._interior(st._tmp[0]); B = dist_slab._interior(st._tmp[1])
+    A.copy_(torch.rand((n, n, n), dtype=torch.float64, device='cuda') * 900 + 20)
+    kappa = mat.k / (mat.rho * mat.cp); gam = kappa * prm.dt / dx ** 2
+    nl = n * n
+    cond = E.vec(6 * nl); call = E.vec(6 * nl * world); xlo = E.vec(nl); xhi = E.vec(nl)
+
+    def tm(fn, k=10):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        ts = []
+        for _ in range(k):
+            e0.record(); fn(); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1))
+        return min(ts)
+    a = tm(lambda: E.condense(0, st.variant, st.Lint, A, st.flags_int, st.packs_int[0], prm.theta, gam, prm.dt, 20.0, cond))
+    call.view(world, -1).copy_(cond.view(1, -1).expand(world, -1))
+    b = tm(lambda: E.interface(call, world, 3, nl, xlo, xhi))
+    c = tm(lambda: E.sweep(0, st.variant, st.Lint, A, st.flags_int, st.packs_int[0], prm.theta, gam, prm.dt, 20.0, B, xlo, xhi))
+    print('pass A %.3f ms, interface %.3f ms, pass B %.3f ms' % (a, b, c))
+
+
+if len(sys.argv) > 3:
+    parts()
