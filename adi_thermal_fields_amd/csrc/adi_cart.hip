@@ -1057,7 +1057,13 @@ static int strided_lines_pref()
 }
 
 static int contig_rows_per_lane(int n) { return n <= 128 ? 2 : (n <= 256 ? 4 : (n <= 512 ? 8 : 16)); }
-static int strided_rows_per_thread(int n) { return n <= 16 ? 2 : (n <= 32 ? 4 : (n <= 512 ? 8 : 16)); }
+static int strided_rows_per_thread(int n)
+{
+    static int m16 = -1;
+    if (m16 < 0) m16 = getenv("ADI_STRIDED_M16") ? 1 : 0;   // tuning knob: 16 rows per thread from n = 257
+    if (m16 && n > 256) return 16;
+    return n <= 16 ? 2 : (n <= 32 ? 4 : (n <= 512 ? 8 : 16));
+}
 
 static LineGeom line_geom(int axis, const Lay &L, long *inner_stride)
 {
@@ -1116,7 +1122,8 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
 static void strided_tiling(int M, const LineGeom &g, int &Lp, int &lines, int &tiles_inner, long &ntiles, size_t &lds)
 {
     Lp = next_pow2((g.n + M - 1) / M);
-    lines = (M <= 8) ? strided_lines_pref() : 8;  // M = 16 keeps 512-thread workgroups (register budget)
+    lines = strided_lines_pref();
+    if (M > 8 && lines * next_pow2((g.n + M - 1) / M) > 512) lines = 8;  // M = 16: 512-thread workgroups (registers)
     while (lines * Lp < 256) lines <<= 1;
     tiles_inner = (g.n_inner + lines - 1) / lines;
     ntiles = (long)tiles_inner * g.n_outer;
