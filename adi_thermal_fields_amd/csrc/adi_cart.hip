@@ -368,11 +368,12 @@ __device__ __forceinline__ void tile_separators(double *sm, int tid, int kk, int
                                                 double bS, double cS, double dS, const Cond &k, double &xL,
                                                 double &xS)
 {
-    // LDS: 8 arrays [LINES][Lp + 1] (one padding column: conflict-free for both access directions)
+    // LDS: 7 arrays [LINES][Lp + 1] (one padding column: conflict-free for both access directions); the
+    // separator values are written over the first array (every thread overwrites the entry it has just read)
     const int ld = Lp + 1;
     const int plane = LINES * ld;
     double *sX1 = sm, *sX2 = sm + plane, *sCS = sm + 2 * plane, *sX4 = sm + 3 * plane;
-    double *sGF = sm + 4 * plane, *sAF = sm + 5 * plane, *sCF = sm + 6 * plane, *sXS = sm + 7 * plane;
+    double *sGF = sm + 4 * plane, *sAF = sm + 5 * plane, *sCF = sm + 6 * plane, *sXS = sm;
     {
         const int w = kk * ld + sg;
         sX1[w] = -aS * k.aL;                          // ra
@@ -1119,62 +1120,100 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
                            dmask, dval, qf, out, L, Lp, s, nunits, queue);
 }
 
-static void strided_tiling(int M, const LineGeom &g, int &Lp, int &lines, int &tiles_inner, long &ntiles, size_t &lds)
+// Tiling of a strided sweep.  `lines` adjacent lines x all segments per workgroup.  The FAST kernel (uniform
+// interior, ~70 VGPRs) takes Mf = 16 rows per thread for n > 256 so that 16 lines (whole 128-byte DRAM bursts per
+// row) still fit a 512-thread workgroup; the GENERAL kernel keeps Mg = 8 rows (register budget) and, when it runs
+// behind a FAST kernel, the same `lines`, so both see the same tile ids in the unit queue.
+struct StridedPlan {
+    int Mg, Lpg;        // GENERAL kernel: rows per thread, segments per line
+    int Mf, Lpf;        // FAST kernel (0 = not available)
+    int lines, tiles_inner;
+    long ntiles;
+    size_t lds_g, lds_f;
+};
+
+static StridedPlan strided_plan(const LineGeom &g, bool want_fast)
 {
-    Lp = next_pow2((g.n + M - 1) / M);
-    lines = strided_lines_pref();
-    if (M > 8 && lines * next_pow2((g.n + M - 1) / M) > 512) lines = 8;  // M = 16: 512-thread workgroups (registers)
-    while (lines * Lp < 256) lines <<= 1;
-    tiles_inner = (g.n_inner + lines - 1) / lines;
-    ntiles = (long)tiles_inner * g.n_outer;
-    lds = (size_t)8 * lines * (Lp + 1) * sizeof(double);
+    StridedPlan P;
+    const int n = g.n;
+    P.Mg = strided_rows_per_thread(n);
+    P.Lpg = next_pow2((n + P.Mg - 1) / P.Mg);
+    P.Mf = 0; P.Lpf = 0;
+    int lines = strided_lines_pref();
+    if (P.Mg > 8 && lines * P.Lpg > 512) lines = 8;
+    if (want_fast && n >= 64) {
+        const int mf = (n > 256) ? 16 : 8;
+        if (n % mf == 0 && n / mf <= 64) {
+            const int lpf = next_pow2(n / mf);
+            int lf = 16;
+            if (lf * lpf > 512) lf = 8;
+            const int tg = lf * P.Lpg;     // threads of the GENERAL kernel on the same tile
+            if (lf * lpf <= 512 && tg <= (P.Mg <= 8 ? 1024 : 512)) {
+                P.Mf = mf; P.Lpf = lpf; lines = lf;
+            }
+        }
+    }
+    while (lines * P.Lpg < 256 && (P.Mf == 0 || lines * P.Lpf < 512)) lines <<= 1;
+    if (P.Mf) while (lines * P.Lpf < 256) lines <<= 1;
+    P.lines = lines;
+    P.tiles_inner = (g.n_inner + lines - 1) / lines;
+    P.ntiles = (long)P.tiles_inner * g.n_outer;
+    P.lds_g = (size_t)7 * lines * (P.Lpg + 1) * sizeof(double);
+    P.lds_f = P.Mf ? (size_t)7 * lines * (P.Lpf + 1) * sizeof(double) : 0;
+    return P;
+}
+
+template <int MF, bool HAS_DIR, bool HAS_Q>
+static void launch_strided_fast(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
+                                const uint8_t *dmask, const double *dval, const double *qf, double *out,
+                                const LineGeom &g, const double *xlo, const double *xhi, SweepScal s, unsigned *queue,
+                                hipStream_t st)
+{
+    hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q>), dim3((unsigned)P.ntiles), dim3(P.lines * P.Lpf),
+                       P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines, P.tiles_inner, P.ntiles,
+                       xlo, xhi, s, queue, make_unic<MF>(s.tg));
 }
 
 template <int M, bool HAS_DIR, bool HAS_Q>
-static void launch_strided(const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
-                           const double *dval, const double *qf, double *out, const LineGeom &g,
-                           const double *xlo, const double *xhi, SweepScal s, void *work, size_t work_bytes,
-                           hipStream_t st)
+static void launch_strided(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
+                           const uint8_t *dmask, const double *dval, const double *qf, double *out, const LineGeom &g,
+                           const double *xlo, const double *xhi, SweepScal s, unsigned *queue, hipStream_t st)
 {
-    int Lp, lines, tiles_inner;
-    long ntiles;
-    size_t lds;
-    strided_tiling(M, g, Lp, lines, tiles_inner, ntiles, lds);
-    const bool fast = use_fast(s, work, work_bytes, ntiles) && (g.n % M == 0) && (lines * Lp <= 512);
-    unsigned *queue = fast ? (unsigned *)work : nullptr;
-    unsigned ggrid = (unsigned)ntiles;
-    if (fast) {
+    unsigned ggrid = (unsigned)P.ntiles;
+    if (queue != nullptr) {
         (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
-        hipLaunchKernelGGL((k_sweep_strided_fast<M, HAS_DIR, HAS_Q>), dim3((unsigned)ntiles), dim3(lines * Lp), lds, st,
-                           in, flags, coeff, dmask, dval, qf, out, g, Lp, lines, tiles_inner, ntiles, xlo, xhi, s, queue,
-                           make_unic<M>(s.tg));
-        ggrid = ntiles < 1024 ? (unsigned)ntiles : 1024u;
+        if (P.Mf == 16) launch_strided_fast<16, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st);
+        else launch_strided_fast<8, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st);
+        ggrid = P.ntiles < 1024 ? (unsigned)P.ntiles : 1024u;
     }
-    hipLaunchKernelGGL((k_sweep_strided<M, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(lines * Lp), lds, st, in, flags, coeff,
-                       dmask, dval, qf, out, g, Lp, lines, tiles_inner, ntiles, xlo, xhi, s, queue);
+    hipLaunchKernelGGL((k_sweep_strided<M, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(P.lines * P.Lpg), P.lds_g, st, in, flags,
+                       coeff, dmask, dval, qf, out, g, P.Lpg, P.lines, P.tiles_inner, P.ntiles, xlo, xhi, s, queue);
+}
+
+template <int MF, bool HAS_DIR, bool HAS_Q>
+static void launch_condense_fast(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
+                                 const uint8_t *dmask, const double *dval, const double *qf, double *cond, long nlines,
+                                 const LineGeom &g, SweepScal s, unsigned *queue, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_condense_strided_fast<MF, HAS_DIR, HAS_Q>), dim3((unsigned)P.ntiles), dim3(P.lines * P.Lpf),
+                       P.lds_f, st, in, flags, coeff, dmask, dval, qf, cond, nlines, g, P.Lpf, P.lines, P.tiles_inner,
+                       P.ntiles, s, queue, make_unic<MF>(s.tg));
 }
 
 template <int M, bool HAS_DIR, bool HAS_Q>
-static void launch_condense(const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
-                            const double *dval, const double *qf, double *cond, long nlines, const LineGeom &g,
-                            SweepScal s, void *work, size_t work_bytes, hipStream_t st)
+static void launch_condense(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
+                            const uint8_t *dmask, const double *dval, const double *qf, double *cond, long nlines,
+                            const LineGeom &g, SweepScal s, unsigned *queue, hipStream_t st)
 {
-    int Lp, lines, tiles_inner;
-    long ntiles;
-    size_t lds;
-    strided_tiling(M, g, Lp, lines, tiles_inner, ntiles, lds);
-    const bool fast = use_fast(s, work, work_bytes, ntiles) && (lines * Lp <= 512);
-    unsigned *queue = fast ? (unsigned *)work : nullptr;
-    unsigned ggrid = (unsigned)ntiles;
-    if (fast) {
+    unsigned ggrid = (unsigned)P.ntiles;
+    if (queue != nullptr) {
         (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
-        hipLaunchKernelGGL((k_condense_strided_fast<M, HAS_DIR, HAS_Q>), dim3((unsigned)ntiles), dim3(lines * Lp), lds,
-                           st, in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, lines, tiles_inner, ntiles, s,
-                           queue, make_unic<M>(s.tg));
-        ggrid = ntiles < 1024 ? (unsigned)ntiles : 1024u;
+        if (P.Mf == 16) launch_condense_fast<16, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st);
+        else launch_condense_fast<8, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st);
+        ggrid = P.ntiles < 1024 ? (unsigned)P.ntiles : 1024u;
     }
-    hipLaunchKernelGGL((k_condense_strided<M, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(lines * Lp), lds, st, in, flags,
-                       coeff, dmask, dval, qf, cond, nlines, g, Lp, lines, tiles_inner, ntiles, s, queue);
+    hipLaunchKernelGGL((k_condense_strided<M, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(P.lines * P.Lpg), P.lds_g, st, in,
+                       flags, coeff, dmask, dval, qf, cond, nlines, g, P.Lpg, P.lines, P.tiles_inner, P.ntiles, s, queue);
 }
 
 template <bool HAS_DIR, bool HAS_Q>
@@ -1203,11 +1242,15 @@ static int sweep_dispatch(int axis, const double *in, const uint8_t *flags, cons
             default: launch_contig<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, work, work_bytes, st); break;
         }
     } else {
-        switch (strided_rows_per_thread(n)) {
-            case 2: launch_strided<2, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, work, work_bytes, st); break;
-            case 4: launch_strided<4, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, work, work_bytes, st); break;
-            case 8: launch_strided<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, work, work_bytes, st); break;
-            default: launch_strided<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, work, work_bytes, st); break;
+        StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr);
+        unsigned *queue = nullptr;
+        if (P.Mf && use_fast(s, work, work_bytes, P.ntiles)) queue = (unsigned *)work;
+        else if (P.Mf) P = strided_plan(g, false);
+        switch (P.Mg) {
+            case 2: launch_strided<2, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st); break;
+            case 4: launch_strided<4, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st); break;
+            case 8: launch_strided<8, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st); break;
+            default: launch_strided<16, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st); break;
         }
     }
     return ADI_OK;
@@ -1222,20 +1265,25 @@ static int condense_dispatch(int axis, const double *in, const uint8_t *flags, c
     const LineGeom g = line_geom(axis, L, &inner_stride);
     const long nlines = (long)g.n_inner * g.n_outer;
     const int n = g.n;
-    int M = 0;
+    bool tiled = false;
+    StridedPlan P;
     if (axis != 2 && n <= kMaxFastLine) {
-        const int pref = strided_rows_per_thread(n);
-        for (int m = pref; m >= 2; m >>= 1)
-            if (n % m == 0 && n / m <= 64) { M = m; break; }
+        P = strided_plan(g, s.sparse != 0 && work != nullptr);
+        tiled = (n % P.Mg == 0) && (n / P.Mg <= 64);     // the tiled kernels need whole segments
     }
-    switch (M) {
-        case 2: launch_condense<2, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, work, work_bytes, st); break;
-        case 4: launch_condense<4, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, work, work_bytes, st); break;
-        case 8: launch_condense<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, work, work_bytes, st); break;
-        case 16: launch_condense<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, work, work_bytes, st); break;
-        default:
-            hipLaunchKernelGGL((k_condense_generic<HAS_DIR, HAS_Q>), dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0,
-                               st, in, flags, coeff, dmask, dval, qf, cond, nlines, g, inner_stride, s);
+    if (tiled) {
+        unsigned *queue = nullptr;
+        if (P.Mf && use_fast(s, work, work_bytes, P.ntiles)) queue = (unsigned *)work;
+        else if (P.Mf) P = strided_plan(g, false);
+        switch (P.Mg) {
+            case 2: launch_condense<2, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st); break;
+            case 4: launch_condense<4, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st); break;
+            case 8: launch_condense<8, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st); break;
+            default: launch_condense<16, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st); break;
+        }
+    } else {
+        hipLaunchKernelGGL((k_condense_generic<HAS_DIR, HAS_Q>), dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0,
+                           st, in, flags, coeff, dmask, dval, qf, cond, nlines, g, inner_stride, s);
     }
     return ADI_OK;
 }
