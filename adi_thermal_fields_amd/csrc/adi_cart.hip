@@ -1057,7 +1057,13 @@ static int strided_lines_pref()
     return v;
 }
 
-static int contig_rows_per_lane(int n) { return n <= 128 ? 2 : (n <= 256 ? 4 : (n <= 512 ? 8 : 16)); }
+static int contig_rows_per_lane(int n)
+{
+    static int m16 = -1;
+    if (m16 < 0) m16 = getenv("ADI_CONTIG_M16") ? 1 : 0;   // tuning knob
+    if (m16 && n > 256 && n % 16 == 0) return 16;
+    return n <= 128 ? 2 : (n <= 256 ? 4 : (n <= 512 ? 8 : 16));
+}
 static int strided_rows_per_thread(int n)
 {
     static int m16 = -1;
