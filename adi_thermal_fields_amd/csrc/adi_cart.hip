@@ -209,17 +209,22 @@ template <int M, bool VEC, bool HAS_DIR, bool HAS_Q>
 __global__ __launch_bounds__(256) void k_sweep_contig(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    double *__restrict__ out, Lay L, int Lp, SweepScal s, long nunits, const unsigned *__restrict__ queue)
+    double *__restrict__ out, Lay L, int Lp, SweepScal s, long nunits, const unsigned *__restrict__ queue,
+    int ratio)
 {
+    // ratio: units of this kernel per queued unit (the FAST kernel may group more lines per wave)
     const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     if (queue == nullptr) {
         const long unit = (long)blockIdx.x * wpb + wave;
         if (unit < nunits)
             contig_unit_general<M, VEC, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, Lp, s, unit);
     } else {
-        const long cnt = queue[0];
-        for (long i = (long)blockIdx.x * wpb + wave; i < cnt; i += (long)gridDim.x * wpb)
-            contig_unit_general<M, VEC, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, Lp, s, queue[1 + i]);
+        const long cnt = (long)queue[0] * ratio;
+        for (long i = (long)blockIdx.x * wpb + wave; i < cnt; i += (long)gridDim.x * wpb) {
+            const long unit = (long)queue[1 + i / ratio] * ratio + (i % ratio);
+            if (unit < nunits)
+                contig_unit_general<M, VEC, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, Lp, s, unit);
+        }
     }
 }
 
@@ -1090,6 +1095,22 @@ static bool use_fast(const SweepScal &s, void *work, size_t work_bytes, long nun
     return !off && s.sparse && work != nullptr && work_bytes >= (size_t)(nunits + 1) * sizeof(unsigned);
 }
 
+template <int MF, bool HAS_DIR, bool HAS_Q>
+static void launch_contig_fast(const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
+                               const double *dval, const double *qf, double *out, const Lay &L, SweepScal s, bool vec,
+                               long nunits_f, unsigned *queue, hipStream_t st)
+{
+    const int Lpf = next_pow2(L.nz / MF);
+    const unsigned grid = (unsigned)((nunits_f + 3) / 4);
+    const UniC<MF> U = make_unic<MF>(s.tg);
+    if (vec)
+        hipLaunchKernelGGL((k_sweep_contig_fast<MF, true, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
+                           dmask, dval, qf, out, L, Lpf, s, nunits_f, queue, U);
+    else
+        hipLaunchKernelGGL((k_sweep_contig_fast<MF, false, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags,
+                           coeff, dmask, dval, qf, out, L, Lpf, s, nunits_f, queue, U);
+}
+
 template <int M, bool HAS_DIR, bool HAS_Q>
 static void launch_contig(const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
                           const double *dval, const double *qf, double *out, const Lay &L, SweepScal s,
@@ -1104,26 +1125,29 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
     const bool aligned = (((uintptr_t)in | (uintptr_t)coeff | (uintptr_t)out | (uintptr_t)dval | (uintptr_t)qf) & 15) == 0 &&
                          (((uintptr_t)flags | (uintptr_t)dmask) & 7) == 0 && (L.sx % 8 == 0);
     const bool vec = aligned && (n % M == 0);
-    const bool fast = use_fast(s, work, work_bytes, nunits) && (n % M == 0);
+    // FAST kernel: 16 rows per lane from n = 257 (two lines per wave: one PCR of 5 steps serves 1024 cells)
+    const int Mf = (n > 256 && n % 16 == 0 && n / 16 <= 64) ? 16 : M;
+    const int lwf = 64 / next_pow2((n + Mf - 1) / Mf);
+    const long nunits_f = (nlines + lwf - 1) / lwf;
+    const bool fast = use_fast(s, work, work_bytes, nunits_f) && (n % Mf == 0) && (lwf % lw == 0);
     unsigned *queue = fast ? (unsigned *)work : nullptr;
     unsigned ggrid = grid;
     if (fast) {
         (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
-        const UniC<M> U = make_unic<M>(s.tg);
-        if (vec)
-            hipLaunchKernelGGL((k_sweep_contig_fast<M, true, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags,
-                               coeff, dmask, dval, qf, out, L, Lp, s, nunits, queue, U);
+        const bool vecf = aligned && (n % Mf == 0);
+        if (Mf == 16 && M != 16)
+            launch_contig_fast<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, vecf, nunits_f, queue, st);
         else
-            hipLaunchKernelGGL((k_sweep_contig_fast<M, false, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags,
-                               coeff, dmask, dval, qf, out, L, Lp, s, nunits, queue, U);
+            launch_contig_fast<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, vecf, nunits_f, queue, st);
         ggrid = grid < 2048u ? grid : 2048u;
     }
+    const int ratio = fast ? lwf / lw : 1;
     if (vec)
         hipLaunchKernelGGL((k_sweep_contig<M, true, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(256), 0, st, in, flags, coeff,
-                           dmask, dval, qf, out, L, Lp, s, nunits, queue);
+                           dmask, dval, qf, out, L, Lp, s, nunits, queue, ratio);
     else
         hipLaunchKernelGGL((k_sweep_contig<M, false, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(256), 0, st, in, flags, coeff,
-                           dmask, dval, qf, out, L, Lp, s, nunits, queue);
+                           dmask, dval, qf, out, L, Lp, s, nunits, queue, ratio);
 }
 
 // Tiling of a strided sweep.  `lines` adjacent lines x all segments per workgroup.  The FAST kernel (uniform
