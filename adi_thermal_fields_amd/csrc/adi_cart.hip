@@ -845,11 +845,20 @@ __device__ __forceinline__ double lap_axis(bool lo, bool hi, double tlo, double 
     return (sacc - cnt * t) * invdx2;
 }
 
-constexpr int kExplicitJR = 8;
+static int explicit_jr()
+{
+    static int v = 0;
+    if (v == 0) {
+        const char *e = getenv("ADI_EXPLICIT_JR");
+        v = e ? atoi(e) : 8;
+        if (v < 1 || v > 64) v = 8;
+    }
+    return v;
+}
 
 __global__ __launch_bounds__(256) void k_explicit_v2(const double *__restrict__ T, const uint8_t *__restrict__ flags,
                                                      double *__restrict__ R0, Lay L, double invdx2, double f,
-                                                     int jslab, int ktiles, long ntiles)
+                                                     int jslab, int ktiles, long ntiles, int kExplicitJR)
 {
 #pragma clang fp contract(off)
     const int nx = L.nx, ny = L.ny, nz = L.nz;
@@ -1409,9 +1418,10 @@ int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, 
         const int jslab = (ny + 7) / 8;
         const int nslab = (ny + jslab - 1) / jslab;
         const int ktiles = (nz + 511) / 512;
+        const int kExplicitJR = explicit_jr();
         const long ntiles = (long)nslab * nx * ((jslab + kExplicitJR - 1) / kExplicitJR) * ktiles;
         hipLaunchKernelGGL(k_explicit_v2, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
-                           L, invdx2, f, jslab, ktiles, ntiles);
+                           L, invdx2, f, jslab, ktiles, ntiles, kExplicitJR);
     } else {
         hipLaunchKernelGGL(k_explicit, dim3(cell_blocks(L)), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0, L,
                            invdx2, f);
