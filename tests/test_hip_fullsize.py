@@ -1,0 +1,74 @@
+"""GPU: BASELINE.json's full-size configurations.
+config 2 (256^3 Robin, 20 steps) is checked against the CPU oracle directly (OpenMP build of the same arithmetic,
+bit-identical to the serial oracle); 512^3 is checked through size-independent properties of the scheme
+(ambient fixed point, linearity of the step in (T, Tinf), mirror symmetry), since the oracle would take minutes."""
+import numpy as np
+import pytest
+
+from helpers import rel_linf
+
+pytestmark = pytest.mark.gpu
+STEEL = dict(rho=7800.0, cp=490.0, k=54.0)
+
+
+def _setup(hip, n, cfl=200.0, dx=5e-4):
+    grid = hip.Grid3D(n, n, n, dx, np.ones((n, n, n), bool))
+    mat = hip.Material(**STEEL)
+    alpha = mat.k / (mat.rho * mat.cp)
+    prm = hip.Params(cfl * dx * dx / alpha, 0.5)
+    packs = hip.precompute_coeff_packs_unified(grid, mat, robin_h=500.0)
+    return grid, mat, prm, packs
+
+
+def test_config2_256_robin_20_steps_vs_oracle():
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from oracle import adi_oracle as orc
+    n = 256
+    grid, mat, prm, packs = _setup(hip, n)
+    T0 = np.random.default_rng(0).uniform(20.0, 1000.0, (n, n, n))
+    T = hip.to_device(T0)
+    for _ in range(20):
+        T = hip.adi_step_hip_coeff(T, grid, mat, prm, packs, Tinf=20.0)
+    og = orc.Grid3D(n, n, n, grid.dx, np.ones((n, n, n), bool))
+    om = orc.Material(**STEEL); op = orc.Params(prm.dt, prm.theta)
+    opacks = orc.precompute_coeff_packs_unified(og, om, robin_h=500.0)
+    want = orc.adi_run(T0, og, om, op, opacks, Tinf=20.0, nsteps=20, omp=True)
+    got = T.get()
+    err = rel_linf(got, want)
+    assert err <= 1e-10, err          # BASELINE.json: <= 1e-10 relative L-inf
+
+
+def test_512_properties():
+    import torch
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    n = 512
+    grid, mat, prm, packs = _setup(hip, n)
+    dev = torch.device('cuda')
+    L = grid.layout
+
+    def step(t, Tinf):
+        return hip.adi_step_hip_coeff(hip.DeviceField(t), grid, mat, prm, packs, Tinf=Tinf).t
+
+    # 1. the ambient temperature is a fixed point of the Robin problem
+    amb = L.empty(); amb.fill_(20.0)
+    out = step(amb, 20.0)
+    assert float((out - 20.0).abs().max()) <= 1e-10
+    # 2. linearity: step(a*T1 + b*T2; a*I1 + b*I2) = a*step(T1; I1) + b*step(T2; I2)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    T1 = L.empty(); T1.copy_(torch.rand((n, n, n), dtype=torch.float64, device=dev, generator=g) * 900 + 20)
+    T2 = L.empty(); T2.copy_(torch.rand((n, n, n), dtype=torch.float64, device=dev, generator=g) * 900 + 20)
+    a, b = 0.75, -1.5
+    lhs = step(a * T1 + b * T2, a * 20.0 + b * 35.0)
+    rhs = a * step(T1, 20.0) + b * step(T2, 35.0)
+    scale = float(rhs.abs().max())
+    assert float((lhs - rhs).abs().max()) / scale <= 1e-11
+    del lhs, rhs
+    # 3. mirror symmetry along every axis (all-solid cube, the same h on all faces)
+    for ax in range(3):
+        f1 = step(torch.flip(T1, dims=(ax,)), 20.0)
+        f2 = torch.flip(step(T1, 20.0), dims=(ax,))
+        assert float((f1 - f2).abs().max()) / scale <= 1e-11, ax
+        del f1, f2
+    # 4. maximum principle: the step cannot leave the range spanned by the field and the ambient
+    o = step(T1, 20.0)
+    assert float(o.max()) <= float(T1.max()) + 1e-9 and float(o.min()) >= 20.0 - 1e-9
