@@ -144,3 +144,34 @@ def test_long_lines_fast_and_general_units(hip, shape):
     got = run_cart_case(hip, c2)['T_final']
     want = run_cart_case(orc, c2)['T_final']
     assert rel_linf(got, want) <= TOL, rel_linf(got, want)
+
+
+def test_random_shapes_and_bcs(hip):
+    """ragged / odd / prime sizes, random masks and BC mixes: every kernel variant and tiling choice
+    (scalar-load instantiations, padded segments, FAST + queued GENERAL units, generic fallbacks)"""
+    from oracle import adi_oracle as orc
+    rng = np.random.default_rng(2026)
+    sizes = [1, 2, 3, 5, 7, 8, 13, 16, 17, 31, 32, 33, 48, 64, 65, 67, 96, 127, 128, 129, 130, 200, 256, 257]
+    worst = 0.0
+    for trial in range(28):
+        shape = tuple(int(rng.choice(sizes)) for _ in range(3))
+        while shape[0] * shape[1] * shape[2] > 600000:
+            shape = tuple(int(rng.choice(sizes)) for _ in range(3))
+        fill = rng.choice([1.0, 0.97, 0.7])
+        mask = rng.random(shape) < fill
+        dx = 1e-3
+        alpha = 54.0 / (7800.0 * 490.0)
+        kind = trial % 4
+        dm = (rng.random(shape) > 0.97) & mask if kind in (0, 2) else None
+        neumann = {'y+': 2e5, 'z-': rng.uniform(0, 3e5, shape)} if kind in (0, 1) else None
+        robin = [None, 300.0, {'x-': 100.0, 'z+': rng.uniform(0, 900, shape)}, rng.uniform(0, 500, shape)][trial % 4]
+        c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,
+                 T0=rng.uniform(20.0, 1200.0, shape), dir_mask=dm, dir_value=(rng.uniform(50, 90, shape) if dm is not None else None),
+                 neumann=neumann, robin_h=robin, Tinf=25.0, theta=float(rng.choice([0.5, 1.0])),
+                 dt=float(rng.choice([0.7, 40.0, 900.0])) * dx * dx / alpha, nsteps=2, births=None)
+        got = run_cart_case(hip, c)['T_final']
+        want = run_cart_case(orc, c)['T_final']
+        err = rel_linf(got, want)
+        worst = max(worst, err)
+        assert err <= TOL, (shape, kind, err)
+    print('worst rel_linf over random cases: %.3e' % worst)
