@@ -926,6 +926,103 @@ __global__ __launch_bounds__(256) void k_explicit_v2(const double *__restrict__ 
     }
 }
 
+// k_explicit_v3: 2.5-D blocking.  A block owns a tile of JT3 j-rows x 512 k and MARCHES ALONG i over a chunk of
+// planes with a three-plane register window, so every T value is loaded from memory once per chunk (plus the two
+// j-halo rows per plane, which the neighbouring tile of the same XCD has just touched); the j-neighbours of a row are
+// in the same thread's registers, the k-neighbours in the adjacent lanes.  Same expression order as v2 / the reference.
+constexpr int JT3 = 4;
+
+__global__ __launch_bounds__(256) void k_explicit_v3(const double *__restrict__ T, const uint8_t *__restrict__ flags,
+                                                     double *__restrict__ R0, Lay L, double invdx2, double f,
+                                                     int jslab, int ktiles, int ichunk, long ntiles)
+{
+#pragma clang fp contract(off)
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
+    const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
+    // tile order: [slab][i-chunk][j-tile in slab][k-tile]
+    const int jt_per_slab = (jslab + JT3 - 1) / JT3;
+    const int nchunk = (nx + ichunk - 1) / ichunk;
+    const long per_chunk = (long)jt_per_slab * ktiles;
+    const long per_slab = per_chunk * nchunk;
+    const int slab = (int)(tile / per_slab);
+    long rem = tile - (long)slab * per_slab;
+    const int ic = (int)(rem / per_chunk);
+    rem -= (long)ic * per_chunk;
+    const int jt = (int)(rem / ktiles), kt = (int)(rem - (long)jt * ktiles);
+    const int j0 = slab * jslab + jt * JT3;
+    int jend = j0 + JT3;
+    if (jend > (slab + 1) * jslab) jend = (slab + 1) * jslab;
+    if (jend > ny) jend = ny;
+    if (j0 >= jend) return;
+    const int i0 = ic * ichunk;
+    const int i1 = (i0 + ichunk < nx) ? i0 + ichunk : nx;
+    const int k0 = kt * 512 + 2 * (int)threadIdx.x;
+    const bool kin = k0 < nz;
+    const int lane = threadIdx.x & 63;
+    const long sx = L.sx, sy = nz;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    double2 tm[JT3], tc[JT3], tp[JT3];
+    const long pbase = (long)j0 * sy + k0;
+#pragma unroll
+    for (int r = 0; r < JT3; ++r) {
+        tm[r] = zero2; tc[r] = zero2; tp[r] = zero2;
+        if (kin && j0 + r < jend) {
+            tc[r] = *reinterpret_cast<const double2 *>(T + (long)i0 * sx + pbase + (long)r * sy);
+            if (i0 > 0) tm[r] = *reinterpret_cast<const double2 *>(T + (long)(i0 - 1) * sx + pbase + (long)r * sy);
+        }
+    }
+    for (int i = i0; i < i1; ++i) {
+        const long p = (long)i * sx + pbase;
+        unsigned fl[JT3];
+        double2 hm = zero2, hp = zero2;
+#pragma unroll
+        for (int r = 0; r < JT3; ++r) {
+            fl[r] = 0;
+            if (kin && j0 + r < jend) {
+                fl[r] = *reinterpret_cast<const uint16_t *>(flags + p + (long)r * sy);
+                if (i + 1 < nx) tp[r] = *reinterpret_cast<const double2 *>(T + p + sx + (long)r * sy);
+            }
+        }
+        if (kin) {
+            if (j0 > 0) hm = *reinterpret_cast<const double2 *>(T + p - sy);
+            if (jend < ny) hp = *reinterpret_cast<const double2 *>(T + p + (long)(jend - j0) * sy);
+        }
+#pragma unroll
+        for (int r = 0; r < JT3; ++r) {
+            const bool rin = j0 + r < jend;
+            const long q = p + (long)r * sy;
+            double kl = __shfl_up(tc[r].y, 1), kr = __shfl_down(tc[r].x, 1);
+            if (lane == 0) kl = (kin && rin && k0 > 0) ? T[q - 1] : 0.0;
+            if (lane == 63) kr = (kin && rin && k0 + 2 < nz) ? T[q + 2] : 0.0;
+            const double2 jm = (r == 0) ? hm : tc[r > 0 ? r - 1 : 0];
+            const double2 jp = (j0 + r + 1 == jend) ? hp : tc[r + 1 < JT3 ? r + 1 : JT3 - 1];
+            const unsigned f0 = fl[r] & 0xffu, f1 = fl[r] >> 8;
+            double r0v, r1v;
+            {
+                double L0 = 0.0, L1 = 0.0, L2 = 0.0;
+                if (f0 & 1u) {
+                    L0 = lap_axis(f0 & 2u, f0 & 4u, tm[r].x, tp[r].x, tc[r].x, invdx2);
+                    L1 = lap_axis(f0 & 8u, f0 & 16u, jm.x, jp.x, tc[r].x, invdx2);
+                    L2 = lap_axis(f0 & 32u, f0 & 64u, kl, tc[r].y, tc[r].x, invdx2);
+                }
+                r0v = tc[r].x + f * ((L0 + L1) + L2);
+            }
+            {
+                double L0 = 0.0, L1 = 0.0, L2 = 0.0;
+                if (f1 & 1u) {
+                    L0 = lap_axis(f1 & 2u, f1 & 4u, tm[r].y, tp[r].y, tc[r].y, invdx2);
+                    L1 = lap_axis(f1 & 8u, f1 & 16u, jm.y, jp.y, tc[r].y, invdx2);
+                    L2 = lap_axis(f1 & 32u, f1 & 64u, tc[r].x, kr, tc[r].y, invdx2);
+                }
+                r1v = tc[r].y + f * ((L0 + L1) + L2);
+            }
+            if (kin && rin) *reinterpret_cast<double2 *>(R0 + q) = make_double2(r0v, r1v);
+        }
+#pragma unroll
+        for (int r = 0; r < JT3; ++r) { tm[r] = tc[r]; tc[r] = tp[r]; }
+    }
+}
+
 // cell index -> (i, j, k, memory offset) for elementwise kernels over a padded-plane layout
 __device__ __forceinline__ bool cell_of(long q, const Lay &L, int &i, int &j, int &k, long &p)
 {
@@ -1418,10 +1515,21 @@ int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, 
         const int jslab = (ny + 7) / 8;
         const int nslab = (ny + jslab - 1) / jslab;
         const int ktiles = (nz + 511) / 512;
-        const int kExplicitJR = explicit_jr();
-        const long ntiles = (long)nslab * nx * ((jslab + kExplicitJR - 1) / kExplicitJR) * ktiles;
-        hipLaunchKernelGGL(k_explicit_v2, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
-                           L, invdx2, f, jslab, ktiles, ntiles, kExplicitJR);
+        static int ver = 0;
+        if (ver == 0) { const char *e = getenv("ADI_EXPLICIT_VER"); ver = e ? atoi(e) : 3; }
+        if (ver == 3) {
+            int ichunk = 32;
+            { const char *e = getenv("ADI_EXPLICIT_ICHUNK"); if (e) ichunk = atoi(e); if (ichunk < 1) ichunk = 32; }
+            const int nchunk = (nx + ichunk - 1) / ichunk;
+            const long ntiles = (long)nslab * nchunk * ((jslab + JT3 - 1) / JT3) * ktiles;
+            hipLaunchKernelGGL(k_explicit_v3, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
+                               L, invdx2, f, jslab, ktiles, ichunk, ntiles);
+        } else {
+            const int kExplicitJR = explicit_jr();
+            const long ntiles = (long)nslab * nx * ((jslab + kExplicitJR - 1) / kExplicitJR) * ktiles;
+            hipLaunchKernelGGL(k_explicit_v2, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
+                               L, invdx2, f, jslab, ktiles, ntiles, kExplicitJR);
+        }
     } else {
         hipLaunchKernelGGL(k_explicit, dim3(cell_blocks(L)), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0, L,
                            invdx2, f);
