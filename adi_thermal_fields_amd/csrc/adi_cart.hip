@@ -460,20 +460,77 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ out, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
-    const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s, const unsigned *__restrict__ queue)
+    const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s, const unsigned *__restrict__ queue,
+    int ratio, int tiles_inner_f)
 {
     extern __shared__ __align__(16) double sm[];
     if (queue == nullptr) {
         strided_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, Lp, LINES, tiles_inner,
                                                 xcd_chunk_tile(blockIdx.x, ntiles), xlo, xhi, s, sm);
     } else {
-        const long cnt = queue[0];
+        // a queued unit is a tile of the FAST kernel = `ratio` adjacent tiles of this kernel
+        const long cnt = (long)queue[0] * ratio;
         for (long i = blockIdx.x; i < cnt; i += gridDim.x) {
-            strided_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, Lp, LINES, tiles_inner,
-                                                    queue[1 + i], xlo, xhi, s, sm);
+            const long u = queue[1 + i / ratio];
+            const long to = u / tiles_inner_f;
+            const long tig = (u - to * tiles_inner_f) * ratio + (i % ratio);
+            if (tig < tiles_inner)
+                strided_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, Lp, LINES, tiles_inner,
+                                                        to * tiles_inner + tig, xlo, xhi, s, sm);
             __syncthreads();   // the LDS arrays are reused by the next tile
         }
     }
+}
+
+// FAST strided kernels, part 1: load the segment's `in` rows and classify it.  Only the flags of row 0 and of the
+// separator row are kept (the interior rows just have to be uniform).
+template <int M, bool HAS_DIR>
+__device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in, const uint8_t *__restrict__ flags,
+                                                  const uint8_t *__restrict__ dmask, const LineGeom &g, long base,
+                                                  int r0, bool active, double (&d)[M], unsigned &f0, unsigned &fS,
+                                                  bool &dirS)
+{
+    bool lane_fast = active && (r0 + M <= g.n);
+    const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
+    f0 = 0; fS = 0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        const bool ok = active && (r0 + r) < g.n;
+        const long p = base + (long)(r0 + r) * g.stride;
+        const unsigned f = ok ? flags[p] : 0u;
+        d[r] = ok ? in[p] : 0.0;
+        if (r == 0) { f0 = f; lane_fast = lane_fast && ((f & ROW0) == ROW0); }
+        else if (r == M - 1) fS = f;
+        else lane_fast = lane_fast && ((f & FULL) == FULL);
+    }
+    dirS = false;
+    if (HAS_DIR) {
+#pragma unroll
+        for (int r = 0; r < M - 1; ++r) lane_fast = lane_fast && (dmask[base + (long)(r0 + r) * g.stride] == 0);
+        dirS = active && (r0 + M - 1) < g.n && dmask[base + (long)(r0 + M - 1) * g.stride] != 0;
+    }
+    return lane_fast;
+}
+
+// part 2: the two general rows of a uniform segment (row 0 and the separator)
+template <int M, bool HAS_DIR, bool HAS_Q>
+__device__ __forceinline__ void fast_segment_ends(const double *__restrict__ coeff, const double *__restrict__ dval,
+                                                  const double *__restrict__ qf, const LineGeom &g, long base, int r0,
+                                                  unsigned f0, unsigned fS, bool dirS, const SweepScal &s,
+                                                  double (&d)[M], double &a0, double &b0, double &aS, double &bS,
+                                                  double &cS)
+{
+    const long p0 = base + (long)r0 * g.stride, pS = base + (long)(r0 + M - 1) * g.stride;
+    const bool e0 = axis_exposed(f0, g.lbit), eS = axis_exposed(fS, g.lbit);
+    const double co0 = e0 ? coeff[p0] : 0.0, coS = eS ? coeff[pS] : 0.0;
+    double q0 = 0.0, qS = 0.0, dvS = 0.0;
+    if (HAS_Q) { q0 = e0 ? qf[p0] : 0.0; qS = eS ? qf[pS] : 0.0; }
+    if (HAS_DIR) dvS = dirS ? dval[pS] : 0.0;
+    double c0;
+    assemble_row<HAS_DIR, HAS_Q>(f0 & 1u, (f0 >> g.lbit) & 1u, (f0 >> (g.lbit + 1)) & 1u, false, d[0], co0, 0.0, q0, s,
+                                 a0, b0, c0, d[0]);
+    assemble_row<HAS_DIR, HAS_Q>(fS & 1u, (fS >> g.lbit) & 1u, (fS >> (g.lbit + 1)) & 1u, dirS, d[M - 1], coS, dvS, qS,
+                                 s, aS, bS, cS, d[M - 1]);
 }
 
 // FAST kernel (sparse packs): tiles whose every segment is uniform-interior (see k_sweep_contig_fast)
@@ -498,41 +555,15 @@ __global__ __launch_bounds__(512) void k_sweep_strided_fast(
     const long line_id = to * (long)g.n_inner + kcol;
 
     double d[M];
-    unsigned fb[M];
-    bool lane_fast = active && (r0 + M <= g.n);
-    const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
-#pragma unroll
-    for (int r = 0; r < M; ++r) {
-        const bool ok = active && (r0 + r) < g.n;
-        const long p = base + (long)(r0 + r) * g.stride;
-        fb[r] = ok ? flags[p] : 0u;
-        d[r] = ok ? in[p] : 0.0;
-    }
-    bool dirS = false;
-    if (HAS_DIR) {
-#pragma unroll
-        for (int r = 0; r < M - 1; ++r)
-            lane_fast = lane_fast && (dmask[base + (long)(r0 + r) * g.stride] == 0 || !(active && (r0 + r) < g.n));
-        dirS = active && (r0 + M - 1) < g.n && dmask[base + (long)(r0 + M - 1) * g.stride] != 0;
-    }
-    lane_fast = lane_fast && ((fb[0] & ROW0) == ROW0);
-#pragma unroll
-    for (int r = 1; r < M - 1; ++r) lane_fast = lane_fast && ((fb[r] & FULL) == FULL);
+    unsigned f0, fS;
+    bool dirS;
+    const bool lane_fast = fast_segment_load<M, HAS_DIR>(in, flags, dmask, g, base, r0, active, d, f0, fS, dirS);
     if (!__syncthreads_and(lane_fast)) {
         if (tid == 0) enqueue_unit(queue, (unsigned)tile);
         return;
     }
-    const long p0 = base + (long)r0 * g.stride, pS = base + (long)(r0 + M - 1) * g.stride;
-    const bool e0 = axis_exposed(fb[0], g.lbit), eS = axis_exposed(fb[M - 1], g.lbit);
-    const double co0 = e0 ? coeff[p0] : 0.0, coS = eS ? coeff[pS] : 0.0;
-    double q0 = 0.0, qS = 0.0, dvS = 0.0;
-    if (HAS_Q) { q0 = e0 ? qf[p0] : 0.0; qS = eS ? qf[pS] : 0.0; }
-    if (HAS_DIR) dvS = dirS ? dval[pS] : 0.0;
-    double a0, b0, c0, aS, bS, cS;
-    assemble_row<HAS_DIR, HAS_Q>(fb[0] & 1u, (fb[0] >> g.lbit) & 1u, (fb[0] >> (g.lbit + 1)) & 1u, false, d[0], co0, 0.0,
-                                 q0, s, a0, b0, c0, d[0]);
-    assemble_row<HAS_DIR, HAS_Q>(fb[M - 1] & 1u, (fb[M - 1] >> g.lbit) & 1u, (fb[M - 1] >> (g.lbit + 1)) & 1u, dirS,
-                                 d[M - 1], coS, dvS, qS, s, aS, bS, cS, d[M - 1]);
+    double a0, b0, aS, bS, cS;
+    fast_segment_ends<M, HAS_DIR, HAS_Q>(coeff, dval, qf, g, base, r0, f0, fS, dirS, s, d, a0, b0, aS, bS, cS);
     if (r0 == 0) {
         if (xlo != nullptr) d[0] = __builtin_fma(-a0, xlo[line_id], d[0]);
         a0 = 0.0;
@@ -620,17 +651,21 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_condense_strided(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ cond, long nlines, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
-    SweepScal s, const unsigned *__restrict__ queue)
+    SweepScal s, const unsigned *__restrict__ queue, int ratio, int tiles_inner_f)
 {
     extern __shared__ __align__(16) double sm[];
     if (queue == nullptr) {
         condense_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, LINES,
                                                  tiles_inner, xcd_chunk_tile(blockIdx.x, ntiles), s, sm);
     } else {
-        const long cnt = queue[0];
+        const long cnt = (long)queue[0] * ratio;
         for (long i = blockIdx.x; i < cnt; i += gridDim.x) {
-            condense_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, LINES,
-                                                     tiles_inner, queue[1 + i], s, sm);
+            const long u = queue[1 + i / ratio];
+            const long to = u / tiles_inner_f;
+            const long tig = (u - to * tiles_inner_f) * ratio + (i % ratio);
+            if (tig < tiles_inner)
+                condense_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, LINES,
+                                                         tiles_inner, to * tiles_inner + tig, s, sm);
             __syncthreads();
         }
     }
@@ -657,40 +692,15 @@ __global__ __launch_bounds__(512) void k_condense_strided_fast(
     const int r0 = sg * M;
 
     double d[M];
-    unsigned fb[M];
-    bool lane_fast = active && (r0 + M <= g.n);
-    const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
-#pragma unroll
-    for (int r = 0; r < M; ++r) {
-        const bool ok = active && (r0 + r) < g.n;
-        const long p = base + (long)(r0 + r) * g.stride;
-        fb[r] = ok ? flags[p] : 0u;
-        d[r] = ok ? in[p] : 0.0;
-    }
-    bool dirS = false;
-    if (HAS_DIR) {
-#pragma unroll
-        for (int r = 0; r < M - 1; ++r) lane_fast = lane_fast && (dmask[base + (long)(r0 + r) * g.stride] == 0);
-        dirS = active && (r0 + M - 1) < g.n && dmask[base + (long)(r0 + M - 1) * g.stride] != 0;
-    }
-    lane_fast = lane_fast && ((fb[0] & ROW0) == ROW0);
-#pragma unroll
-    for (int r = 1; r < M - 1; ++r) lane_fast = lane_fast && ((fb[r] & FULL) == FULL);
+    unsigned f0, fS;
+    bool dirS;
+    const bool lane_fast = fast_segment_load<M, HAS_DIR>(in, flags, dmask, g, base, r0, active, d, f0, fS, dirS);
     if (!__syncthreads_and(lane_fast)) {
         if (tid == 0) enqueue_unit(queue, (unsigned)tile);
         return;
     }
-    const long p0 = base + (long)r0 * g.stride, pS = base + (long)(r0 + M - 1) * g.stride;
-    const bool e0 = axis_exposed(fb[0], g.lbit), eS = axis_exposed(fb[M - 1], g.lbit);
-    const double co0 = e0 ? coeff[p0] : 0.0, coS = eS ? coeff[pS] : 0.0;
-    double q0 = 0.0, qS = 0.0, dvS = 0.0;
-    if (HAS_Q) { q0 = e0 ? qf[p0] : 0.0; qS = eS ? qf[pS] : 0.0; }
-    if (HAS_DIR) dvS = dirS ? dval[pS] : 0.0;
-    double a0, b0, c0, aS, bS, cS;
-    assemble_row<HAS_DIR, HAS_Q>(fb[0] & 1u, (fb[0] >> g.lbit) & 1u, (fb[0] >> (g.lbit + 1)) & 1u, false, d[0], co0, 0.0,
-                                 q0, s, a0, b0, c0, d[0]);
-    assemble_row<HAS_DIR, HAS_Q>(fb[M - 1] & 1u, (fb[M - 1] >> g.lbit) & 1u, (fb[M - 1] >> (g.lbit + 1)) & 1u, dirS,
-                                 d[M - 1], coS, dvS, qS, s, aS, bS, cS, d[M - 1]);
+    double a0, b0, aS, bS, cS;
+    fast_segment_ends<M, HAS_DIR, HAS_Q>(coeff, dval, qf, g, base, r0, f0, fS, dirS, s, d, a0, b0, aS, bS, cS);
     Cond ki;
     double kappa;
     condense_uniform<M>(U, a0, b0, d, ki, kappa);
@@ -1261,41 +1271,55 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
 // row) still fit a 512-thread workgroup; the GENERAL kernel keeps Mg = 8 rows (register budget) and, when it runs
 // behind a FAST kernel, the same `lines`, so both see the same tile ids in the unit queue.
 struct StridedPlan {
-    int Mg, Lpg;        // GENERAL kernel: rows per thread, segments per line
-    int Mf, Lpf;        // FAST kernel (0 = not available)
-    int lines, tiles_inner;
-    long ntiles;
+    int Mg, Lpg, lines_g, tiles_inner_g;    // GENERAL kernel: rows per thread, segments per line, lines per tile
+    long ntiles_g;
+    int Mf, Lpf, lines_f, tiles_inner_f;    // FAST kernel (Mf = 0: not available)
+    long ntiles_f;
+    int ratio;                              // lines_f / lines_g: GENERAL tiles per queued FAST tile
     size_t lds_g, lds_f;
 };
 
+// Tiling of a strided sweep: `lines` adjacent lines x all segments per workgroup.  The pure-streaming rate of this
+// access pattern grows with the contiguous bytes per row (measured at 17 B/cell: 16 lines 4.3 TB/s, 32 lines
+// 5.1 TB/s), so the FAST kernel (uniform interior, registers only for `in`) takes n/16 rows per thread and 32 lines
+// in a 512-thread workgroup; the GENERAL kernel keeps 8 rows per thread (register budget) on tiles of 16 or 32 of
+// the same lines, `ratio` of them per FAST tile.
 static StridedPlan strided_plan(const LineGeom &g, bool want_fast)
 {
     StridedPlan P;
     const int n = g.n;
     P.Mg = strided_rows_per_thread(n);
     P.Lpg = next_pow2((n + P.Mg - 1) / P.Mg);
-    P.Mf = 0; P.Lpf = 0;
+    P.Mf = 0; P.Lpf = 0; P.lines_f = 0; P.tiles_inner_f = 0; P.ntiles_f = 0; P.ratio = 1; P.lds_f = 0;
     int lines = strided_lines_pref();
     if (P.Mg > 8 && lines * P.Lpg > 512) lines = 8;
+    const int maxg = (P.Mg <= 8) ? 1024 : 512;
     if (want_fast && n >= 64) {
-        const int mf = (n > 256) ? 16 : 8;
-        if (n % mf == 0 && n / mf <= 64) {
+        int mf = 0, lf = 0;
+        if (n % 16 == 0 && (n / 16 == 8 || n / 16 == 16 || n / 16 == 32)) { mf = n / 16; lf = 32; }   // Lpf = 16
+        else {
+            const int m2 = (n > 256) ? 16 : 8;
+            if (n % m2 == 0 && n / m2 <= 64) { mf = m2; lf = (16 * next_pow2(n / m2) > 512) ? 8 : 16; }
+        }
+        if (mf) {
             const int lpf = next_pow2(n / mf);
-            int lf = 16;
-            if (lf * lpf > 512) lf = 8;
-            const int tg = lf * P.Lpg;     // threads of the GENERAL kernel on the same tile
-            if (lf * lpf <= 512 && tg <= (P.Mg <= 8 ? 1024 : 512)) {
-                P.Mf = mf; P.Lpf = lpf; lines = lf;
+            int lg = lf;                                  // GENERAL lines: lf, or lf/2 when the workgroup gets too big
+            while (lg * P.Lpg > maxg && lg > 8) lg >>= 1;
+            if (lf * lpf <= 512 && lf * lpf >= 256 && lg * P.Lpg <= maxg && lg * P.Lpg >= 64) {
+                P.Mf = mf; P.Lpf = lpf; P.lines_f = lf; lines = lg; P.ratio = lf / lg;
             }
         }
     }
-    while (lines * P.Lpg < 256 && (P.Mf == 0 || lines * P.Lpf < 512)) lines <<= 1;
-    if (P.Mf) while (lines * P.Lpf < 256) lines <<= 1;
-    P.lines = lines;
-    P.tiles_inner = (g.n_inner + lines - 1) / lines;
-    P.ntiles = (long)P.tiles_inner * g.n_outer;
+    if (P.Mf == 0) while (lines * P.Lpg < 256) lines <<= 1;
+    P.lines_g = lines;
+    P.tiles_inner_g = (g.n_inner + lines - 1) / lines;
+    P.ntiles_g = (long)P.tiles_inner_g * g.n_outer;
     P.lds_g = (size_t)7 * lines * (P.Lpg + 1) * sizeof(double);
-    P.lds_f = P.Mf ? (size_t)7 * lines * (P.Lpf + 1) * sizeof(double) : 0;
+    if (P.Mf) {
+        P.tiles_inner_f = (g.n_inner + P.lines_f - 1) / P.lines_f;
+        P.ntiles_f = (long)P.tiles_inner_f * g.n_outer;
+        P.lds_f = (size_t)7 * P.lines_f * (P.Lpf + 1) * sizeof(double);
+    }
     return P;
 }
 
@@ -1305,9 +1329,9 @@ static void launch_strided_fast(const StridedPlan &P, const double *in, const ui
                                 const LineGeom &g, const double *xlo, const double *xhi, SweepScal s, unsigned *queue,
                                 hipStream_t st)
 {
-    hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q>), dim3((unsigned)P.ntiles), dim3(P.lines * P.Lpf),
-                       P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines, P.tiles_inner, P.ntiles,
-                       xlo, xhi, s, queue, make_unic<MF>(s.tg));
+    hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q>), dim3((unsigned)P.ntiles_f), dim3(P.lines_f * P.Lpf),
+                       P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f, P.tiles_inner_f,
+                       P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg));
 }
 
 template <int M, bool HAS_DIR, bool HAS_Q>
@@ -1315,15 +1339,17 @@ static void launch_strided(const StridedPlan &P, const double *in, const uint8_t
                            const uint8_t *dmask, const double *dval, const double *qf, double *out, const LineGeom &g,
                            const double *xlo, const double *xhi, SweepScal s, unsigned *queue, hipStream_t st)
 {
-    unsigned ggrid = (unsigned)P.ntiles;
+    unsigned ggrid = (unsigned)P.ntiles_g;
     if (queue != nullptr) {
         (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
-        if (P.Mf == 16) launch_strided_fast<16, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st);
+        if (P.Mf == 32) launch_strided_fast<32, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st);
+        else if (P.Mf == 16) launch_strided_fast<16, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st);
         else launch_strided_fast<8, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st);
-        ggrid = P.ntiles < 1024 ? (unsigned)P.ntiles : 1024u;
+        ggrid = P.ntiles_g < 1024 ? (unsigned)P.ntiles_g : 1024u;
     }
-    hipLaunchKernelGGL((k_sweep_strided<M, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(P.lines * P.Lpg), P.lds_g, st, in, flags,
-                       coeff, dmask, dval, qf, out, g, P.Lpg, P.lines, P.tiles_inner, P.ntiles, xlo, xhi, s, queue);
+    hipLaunchKernelGGL((k_sweep_strided<M, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(P.lines_g * P.Lpg), P.lds_g, st, in,
+                       flags, coeff, dmask, dval, qf, out, g, P.Lpg, P.lines_g, P.tiles_inner_g, P.ntiles_g, xlo, xhi,
+                       s, queue, P.ratio, P.tiles_inner_f);
 }
 
 template <int MF, bool HAS_DIR, bool HAS_Q>
@@ -1331,9 +1357,9 @@ static void launch_condense_fast(const StridedPlan &P, const double *in, const u
                                  const uint8_t *dmask, const double *dval, const double *qf, double *cond, long nlines,
                                  const LineGeom &g, SweepScal s, unsigned *queue, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_condense_strided_fast<MF, HAS_DIR, HAS_Q>), dim3((unsigned)P.ntiles), dim3(P.lines * P.Lpf),
-                       P.lds_f, st, in, flags, coeff, dmask, dval, qf, cond, nlines, g, P.Lpf, P.lines, P.tiles_inner,
-                       P.ntiles, s, queue, make_unic<MF>(s.tg));
+    hipLaunchKernelGGL((k_condense_strided_fast<MF, HAS_DIR, HAS_Q>), dim3((unsigned)P.ntiles_f),
+                       dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, cond, nlines, g, P.Lpf,
+                       P.lines_f, P.tiles_inner_f, P.ntiles_f, s, queue, make_unic<MF>(s.tg));
 }
 
 template <int M, bool HAS_DIR, bool HAS_Q>
@@ -1341,15 +1367,17 @@ static void launch_condense(const StridedPlan &P, const double *in, const uint8_
                             const uint8_t *dmask, const double *dval, const double *qf, double *cond, long nlines,
                             const LineGeom &g, SweepScal s, unsigned *queue, hipStream_t st)
 {
-    unsigned ggrid = (unsigned)P.ntiles;
+    unsigned ggrid = (unsigned)P.ntiles_g;
     if (queue != nullptr) {
         (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
-        if (P.Mf == 16) launch_condense_fast<16, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st);
+        if (P.Mf == 32) launch_condense_fast<32, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st);
+        else if (P.Mf == 16) launch_condense_fast<16, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st);
         else launch_condense_fast<8, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st);
-        ggrid = P.ntiles < 1024 ? (unsigned)P.ntiles : 1024u;
+        ggrid = P.ntiles_g < 1024 ? (unsigned)P.ntiles_g : 1024u;
     }
-    hipLaunchKernelGGL((k_condense_strided<M, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(P.lines * P.Lpg), P.lds_g, st, in,
-                       flags, coeff, dmask, dval, qf, cond, nlines, g, P.Lpg, P.lines, P.tiles_inner, P.ntiles, s, queue);
+    hipLaunchKernelGGL((k_condense_strided<M, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(P.lines_g * P.Lpg), P.lds_g, st, in,
+                       flags, coeff, dmask, dval, qf, cond, nlines, g, P.Lpg, P.lines_g, P.tiles_inner_g, P.ntiles_g, s,
+                       queue, P.ratio, P.tiles_inner_f);
 }
 
 template <bool HAS_DIR, bool HAS_Q>
@@ -1380,7 +1408,7 @@ static int sweep_dispatch(int axis, const double *in, const uint8_t *flags, cons
     } else {
         StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr);
         unsigned *queue = nullptr;
-        if (P.Mf && use_fast(s, work, work_bytes, P.ntiles)) queue = (unsigned *)work;
+        if (P.Mf && use_fast(s, work, work_bytes, P.ntiles_f)) queue = (unsigned *)work;
         else if (P.Mf) P = strided_plan(g, false);
         switch (P.Mg) {
             case 2: launch_strided<2, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st); break;
@@ -1409,7 +1437,7 @@ static int condense_dispatch(int axis, const double *in, const uint8_t *flags, c
     }
     if (tiled) {
         unsigned *queue = nullptr;
-        if (P.Mf && use_fast(s, work, work_bytes, P.ntiles)) queue = (unsigned *)work;
+        if (P.Mf && use_fast(s, work, work_bytes, P.ntiles_f)) queue = (unsigned *)work;
         else if (P.Mf) P = strided_plan(g, false);
         switch (P.Mg) {
             case 2: launch_condense<2, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st); break;
