@@ -1284,7 +1284,7 @@ struct StridedPlan {
 // 5.1 TB/s), so the FAST kernel (uniform interior, registers only for `in`) takes n/16 rows per thread and 32 lines
 // in a 512-thread workgroup; the GENERAL kernel keeps 8 rows per thread (register budget) on tiles of 16 or 32 of
 // the same lines, `ratio` of them per FAST tile.
-static StridedPlan strided_plan(const LineGeom &g, bool want_fast)
+static StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok)
 {
     StridedPlan P;
     const int n = g.n;
@@ -1296,7 +1296,9 @@ static StridedPlan strided_plan(const LineGeom &g, bool want_fast)
     const int maxg = (P.Mg <= 8) ? 1024 : 512;
     if (want_fast && n >= 64) {
         int mf = 0, lf = 0;
-        if (n % 16 == 0 && (n / 16 == 8 || n / 16 == 16 || n / 16 == 32)) { mf = n / 16; lf = 32; }   // Lpf = 16
+        // 32-line tiles with n/16 rows per thread: only where the kernel keeps few arrays alive (pass A); the solve
+        // kernel needs > 200 VGPRs at 32 rows per thread and runs faster on 16-line tiles with 16 rows
+        if (wide_ok && n % 16 == 0 && (n / 16 == 8 || n / 16 == 16 || n / 16 == 32)) { mf = n / 16; lf = 32; }   // Lpf = 16
         else {
             const int m2 = (n > 256) ? 16 : 8;
             if (n % m2 == 0 && n / m2 <= 64) { mf = m2; lf = (16 * next_pow2(n / m2) > 512) ? 8 : 16; }
@@ -1406,10 +1408,10 @@ static int sweep_dispatch(int axis, const double *in, const uint8_t *flags, cons
             default: launch_contig<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, work, work_bytes, st); break;
         }
     } else {
-        StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr);
+        StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr, false);
         unsigned *queue = nullptr;
         if (P.Mf && use_fast(s, work, work_bytes, P.ntiles_f)) queue = (unsigned *)work;
-        else if (P.Mf) P = strided_plan(g, false);
+        else if (P.Mf) P = strided_plan(g, false, false);
         switch (P.Mg) {
             case 2: launch_strided<2, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st); break;
             case 4: launch_strided<4, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st); break;
@@ -1432,13 +1434,13 @@ static int condense_dispatch(int axis, const double *in, const uint8_t *flags, c
     bool tiled = false;
     StridedPlan P;
     if (axis != 2 && n <= kMaxFastLine) {
-        P = strided_plan(g, s.sparse != 0 && work != nullptr);
+        P = strided_plan(g, s.sparse != 0 && work != nullptr, true);
         tiled = (n % P.Mg == 0) && (n / P.Mg <= 64);     // the tiled kernels need whole segments
     }
     if (tiled) {
         unsigned *queue = nullptr;
         if (P.Mf && use_fast(s, work, work_bytes, P.ntiles_f)) queue = (unsigned *)work;
-        else if (P.Mf) P = strided_plan(g, false);
+        else if (P.Mf) P = strided_plan(g, false, false);
         switch (P.Mg) {
             case 2: launch_condense<2, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st); break;
             case 4: launch_condense<4, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st); break;
