@@ -293,15 +293,14 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     const double xS = pcr_solve(ra, rb, rc, rd, li, Lp);
     double xL = __shfl_up(xS, 1, Lp);
     if (li == 0) xL = 0.0;
-    double x[M];
-    back_solve_uniform<M>(U, a0, kappa, d, xL, xS, x);
+    back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
     if (VEC) {
         double2 *q = reinterpret_cast<double2 *>(out + base);
 #pragma unroll
-        for (int i = 0; i < M / 2; ++i) q[i] = make_double2(x[2 * i], x[2 * i + 1]);
+        for (int i = 0; i < M / 2; ++i) q[i] = make_double2(d[2 * i], d[2 * i + 1]);
     } else {
 #pragma unroll
-        for (int r = 0; r < M; ++r) out[base + r] = x[r];
+        for (int r = 0; r < M; ++r) out[base + r] = d[r];
     }
 }
 
@@ -484,9 +483,11 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
 
 // FAST strided kernels, part 1: load the segment's `in` rows and classify it.  Only the flags of row 0 and of the
 // separator row are kept (the interior rows just have to be uniform).
+// Addressing: element (row sg*M + r, column kcol) = [tile base + r*stride] (block-uniform -> scalar registers)
+//             + voff, voff = sg*M*stride + kk a per-thread 32-bit offset that is the same for every row and array.
 template <int M, bool HAS_DIR>
-__device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in, const uint8_t *__restrict__ flags,
-                                                  const uint8_t *__restrict__ dmask, const LineGeom &g, long base,
+__device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in_t, const uint8_t *__restrict__ flags_t,
+                                                  const uint8_t *__restrict__ dmask_t, const LineGeom &g, unsigned voff,
                                                   int r0, bool active, double (&d)[M], unsigned &f0, unsigned &fS,
                                                   bool &dirS)
 {
@@ -496,9 +497,8 @@ __device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in,
 #pragma unroll
     for (int r = 0; r < M; ++r) {
         const bool ok = active && (r0 + r) < g.n;
-        const long p = base + (long)(r0 + r) * g.stride;
-        const unsigned f = ok ? flags[p] : 0u;
-        d[r] = ok ? in[p] : 0.0;
+        const unsigned f = ok ? (flags_t + (size_t)r * g.stride)[voff] : 0u;
+        d[r] = ok ? (in_t + (size_t)r * g.stride)[voff] : 0.0;
         if (r == 0) { f0 = f; lane_fast = lane_fast && ((f & ROW0) == ROW0); }
         else if (r == M - 1) fS = f;
         else lane_fast = lane_fast && ((f & FULL) == FULL);
@@ -506,8 +506,9 @@ __device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in,
     dirS = false;
     if (HAS_DIR) {
 #pragma unroll
-        for (int r = 0; r < M - 1; ++r) lane_fast = lane_fast && (dmask[base + (long)(r0 + r) * g.stride] == 0);
-        dirS = active && (r0 + M - 1) < g.n && dmask[base + (long)(r0 + M - 1) * g.stride] != 0;
+        for (int r = 0; r < M - 1; ++r)
+            lane_fast = lane_fast && ((dmask_t + (size_t)r * g.stride)[voff] == 0);
+        dirS = active && (r0 + M - 1) < g.n && (dmask_t + (size_t)(M - 1) * g.stride)[voff] != 0;
     }
     return lane_fast;
 }
@@ -557,7 +558,11 @@ __global__ __launch_bounds__(512) void k_sweep_strided_fast(
     double d[M];
     unsigned f0, fS;
     bool dirS;
-    const bool lane_fast = fast_segment_load<M, HAS_DIR>(in, flags, dmask, g, base, r0, active, d, f0, fS, dirS);
+    // block-uniform tile base (scalar) + one 32-bit per-thread offset for every row of every array
+    const long tbase = to * g.outer_stride + (long)ti * LINES;
+    const unsigned voff = (unsigned)((long)r0 * g.stride + kk);
+    const bool lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g,
+                                                         voff, r0, active, d, f0, fS, dirS);
     if (!__syncthreads_and(lane_fast)) {
         if (tid == 0) enqueue_unit(queue, (unsigned)tile);
         return;
@@ -577,10 +582,10 @@ __global__ __launch_bounds__(512) void k_sweep_strided_fast(
     condense_uniform<M>(U, a0, b0, d, k, kappa);
     double xL, xS;
     tile_separators(sm, tid, kk, sg, Lp, LINES, aS, bS, cS, d[M - 1], k, xL, xS);
-    double x[M];
-    back_solve_uniform<M>(U, a0, kappa, d, xL, xS, x);
+    back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
+    double *out_t = out + tbase;
 #pragma unroll
-    for (int r = 0; r < M; ++r) out[base + (long)(r0 + r) * g.stride] = x[r];
+    for (int r = 0; r < M; ++r) (out_t + (size_t)r * g.stride)[voff] = d[r];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -694,7 +699,11 @@ __global__ __launch_bounds__(512) void k_condense_strided_fast(
     double d[M];
     unsigned f0, fS;
     bool dirS;
-    const bool lane_fast = fast_segment_load<M, HAS_DIR>(in, flags, dmask, g, base, r0, active, d, f0, fS, dirS);
+    // block-uniform tile base (scalar) + one 32-bit per-thread offset for every row of every array
+    const long tbase = to * g.outer_stride + (long)ti * LINES;
+    const unsigned voff = (unsigned)((long)r0 * g.stride + kk);
+    const bool lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g,
+                                                         voff, r0, active, d, f0, fS, dirS);
     if (!__syncthreads_and(lane_fast)) {
         if (tid == 0) enqueue_unit(queue, (unsigned)tile);
         return;
@@ -1294,7 +1303,7 @@ static StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok)
     int lines = strided_lines_pref();
     if (P.Mg > 8 && lines * P.Lpg > 512) lines = 8;
     const int maxg = (P.Mg <= 8) ? 1024 : 512;
-    if (want_fast && n >= 64) {
+    if (want_fast && n >= 64 && (long)n * g.stride < (1L << 31)) {   // 32-bit element offsets in the FAST kernels
         int mf = 0, lf = 0;
         // 32-line tiles with n/16 rows per thread: only where the kernel keeps few arrays alive (pass A); the solve
         // kernel needs > 200 VGPRs at 32 rows per thread and runs faster on 16-line tiles with 16 rows
@@ -1408,7 +1417,9 @@ static int sweep_dispatch(int axis, const double *in, const uint8_t *flags, cons
             default: launch_contig<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, work, work_bytes, st); break;
         }
     } else {
-        StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr, false);
+        static int wide = -1;
+        if (wide < 0) wide = getenv("ADI_STRIDED_WIDE") ? atoi(getenv("ADI_STRIDED_WIDE")) : 0;
+        StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr, wide != 0);
         unsigned *queue = nullptr;
         if (P.Mf && use_fast(s, work, work_bytes, P.ntiles_f)) queue = (unsigned *)work;
         else if (P.Mf) P = strided_plan(g, false, false);

@@ -170,23 +170,23 @@ __device__ __forceinline__ void condense_uniform(const UniC<M> &U, double a0, do
     k.cL = U.s * __builtin_fma(-kpl, pl, U.p[0]);
 }
 
+// in place: on entry d = right-hand sides of the M rows, on exit d = solution (row M-1 = xS)
 template <int M>
-__device__ __forceinline__ void back_solve_uniform(const UniC<M> &U, double a0, double kappa, const double (&d)[M],
-                                                   double xL, double xS, double (&x)[M])
+__device__ __forceinline__ void back_solve_uniform(const UniC<M> &U, double a0, double kappa, double (&d)[M],
+                                                   double xL, double xS)
 {
     constexpr int MI = M - 1;
-    double y[MI];
-    y[0] = __builtin_fma(-a0, xL, d[0]);
+    d[0] = __builtin_fma(-a0, xL, d[0]);
 #pragma unroll
-    for (int r = 1; r < MI; ++r) y[r] = __builtin_fma(-U.w[r], y[r - 1], d[r]);
-    y[MI - 1] = __builtin_fma(-U.s, xS, y[MI - 1]);
-    x[MI - 1] = y[MI - 1] * U.ip[MI - 1];
+    for (int r = 1; r < MI; ++r) d[r] = __builtin_fma(-U.w[r], d[r - 1], d[r]);
+    d[MI - 1] = __builtin_fma(-U.s, xS, d[MI - 1]);
+    d[MI - 1] = d[MI - 1] * U.ip[MI - 1];
 #pragma unroll
-    for (int r = MI - 2; r >= 0; --r) x[r] = __builtin_fma(-U.s, x[r + 1], y[r]) * U.ip[r];
-    const double t = kappa * x[0];
+    for (int r = MI - 2; r >= 0; --r) d[r] = __builtin_fma(-U.s, d[r + 1], d[r]) * U.ip[r];
+    const double t = kappa * d[0];
 #pragma unroll
-    for (int r = 0; r < MI; ++r) x[r] = __builtin_fma(-t, U.p[r], x[r]);
-    x[M - 1] = xS;
+    for (int r = 0; r < MI; ++r) d[r] = __builtin_fma(-t, U.p[r], d[r]);
+    d[M - 1] = xS;
 }
 
 // host: constants for (s, bu)
