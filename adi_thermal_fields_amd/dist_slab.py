@@ -293,7 +293,8 @@ class SlabStepper:
                 nl = (j1 - j0) * self.nz
                 self._chunk_bufs.append(dict(L=E.layout(self.nxl, j1 - j0, self.nz, self.Lint.sx), nl=nl, cond=E.vec(6 * nl),
                                              cond_all=E.vec(6 * nl * self.world), xlo=E.vec(nl), xhi=E.vec(nl)))
-            self._use_streams = (E.device.type == 'cuda') and isinstance(self.comm, TorchDistComm)
+            self._use_streams = (E.device.type == 'cuda') and isinstance(self.comm, TorchDistComm) \
+                and not getattr(self, '_no_overlap', False)
             if self._use_streams:
                 self._comm_stream = torch.cuda.Stream(device=E.device)
         return self._chunk_list
@@ -328,6 +329,25 @@ class SlabStepper:
             E.interface(cb['cond_all'], self.world, self.rank, cb['nl'], cb['xlo'], cb['xhi'])
             E.sweep(0, v, cb['L'], sub(Ai, j0, j1), sub(fl, j0, j1), tuple(sub(t, j0, j1) for t in pk), prm.theta, gam,
                     prm.dt, self.Tinf, sub(Bi, j0, j1), cb['xlo'], cb['xhi'])
+
+    def self_check(self, T):
+        """One step with the second-stream pipeline and one with every exchange on the main stream, from the same
+        input; they must agree to rounding.  If they do not (a stream-ordering problem on this software stack), the
+        pipeline is switched off for the rest of the run.  Returns (max relative difference, overlap enabled)."""
+        t = T.t if hasattr(T, 't') and not isinstance(T, torch.Tensor) else T
+        src = t.clone()
+        a = self.step(src)
+        a = (a.t if hasattr(a, 't') and not isinstance(a, torch.Tensor) else a).clone()
+        self._no_overlap = True
+        self._chunk_list = None
+        b = self.step(src)
+        b = b.t if hasattr(b, 't') and not isinstance(b, torch.Tensor) else b
+        den = float(b.abs().max())
+        err = float((a - b).abs().max()) / (den if den > 0 else 1.0)
+        if err <= 1e-12:
+            self._no_overlap = False
+            self._chunk_list = None
+        return err, not self._no_overlap
 
     def step(self, T, events=None):
         E, prm, mat = self.engine, self.params, self.mat

@@ -111,6 +111,7 @@ def main():
         T = adi.DeviceField(T0)
         variant = stepper.variant
         stage_names = stepper.stage_names
+        overlap_err, overlap_on = stepper.self_check(T)     # pipeline on the second stream vs plain ordering
 
     def sync():
         if world > 1:
@@ -192,6 +193,7 @@ def main():
                     sweep_variant={0: 'general', 1: 'no_dir', 2: 'no_q', 3: 'lean'}[variant]),
         cell_updates_per_s=round(world * N * a.steps / elapsed, 1),
         step_achieved_gbs=round(sum(bytes_per_cell.values()) * N / (ms_per_step * 1e-3) / 1e9, 1),
+        **({'comm_overlap': dict(enabled=overlap_on, selfcheck_rel_diff=overlap_err)} if world > 1 else {}),
         roofline=dict(bound='hbm', kernel=dom, achieved=kernels[dom]['achieved_gbs'], peak=HBM_PEAK_GBS,
                       unit='GB/s', frac=kernels[dom]['frac'], traffic=traffic),
         kernels=kernels,
