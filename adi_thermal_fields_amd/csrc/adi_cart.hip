@@ -140,94 +140,6 @@ __device__ __forceinline__ void enqueue_unit(unsigned *queue, unsigned unit)
     queue[1 + idx] = unit;
 }
 
-// GENERAL body for one wave-unit (unit = index of a group of 64/Lp consecutive lines)
-template <int M, bool VEC, bool HAS_DIR, bool HAS_Q>
-__device__ __forceinline__ void contig_unit_general(
-    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
-    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    double *__restrict__ out, const Lay &L, int Lp, const SweepScal &s, long unit)
-{
-    const int n = L.nz;
-    const long nlines = (long)L.nx * L.ny;
-    const int lane = threadIdx.x & 63;
-    const int lw = 64 / Lp;  // lines per wave
-    const int li = lane & (Lp - 1);
-    const long line = unit * lw + (lane / Lp);
-    const bool active = line < nlines;
-    const int r0 = li * M;
-    const long pi = line / L.ny;
-    const long base = pi * L.sx + (line - pi * L.ny) * (long)n + r0;
-
-    double vin[M], vco[M], vdv[M], vq[M];
-    unsigned fb[M], db[M];
-    load_bytes_contig<M, VEC>(flags, base, r0, n, active, fb);
-    if (HAS_DIR) load_bytes_contig<M, VEC>(dmask, base, r0, n, active, db);
-    load_rows_contig<M, VEC>(in, base, r0, n, active, vin);
-    {
-        bool need = !s.sparse, needd = !s.sparse;
-#pragma unroll
-        for (int r = 0; r < M; ++r) {
-            need = need || axis_exposed(fb[r], 5);
-            if (HAS_DIR) needd = needd || (db[r] != 0);
-        }
-        load_rows_contig<M, VEC>(coeff, base, r0, n, active && need, vco);
-        if (HAS_Q) load_rows_contig<M, VEC>(qf, base, r0, n, active && need, vq);
-        if (HAS_DIR) load_rows_contig<M, VEC>(dval, base, r0, n, active && needd, vdv);
-    }
-    double a[M], b[M], c[M], d[M];
-#pragma unroll
-    for (int r = 0; r < M; ++r)   // flags: bit0 cell in mask, bit5 / bit6 the z- / z+ neighbour is in the mask
-        assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> 5) & 1u, (fb[r] >> 6) & 1u, HAS_DIR && db[r] != 0, vin[r],
-                                     vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r], c[r], d[r]);
-    double ip[M - 1];
-    Cond k;
-    condense<M>(a, b, c, d, ip, k);
-    // first-row data of the next segment of the same line
-    const double gFn = __shfl_down(k.gF, 1, Lp), aFn = __shfl_down(k.aF, 1, Lp), cFn = __shfl_down(k.cF, 1, Lp);
-    double ra, rb, rc, rd;
-    reduced_row(a[M - 1], b[M - 1], c[M - 1], d[M - 1], k, gFn, aFn, cFn, ra, rb, rc, rd);
-    const double xS = pcr_solve(ra, rb, rc, rd, li, Lp);
-    double xL = __shfl_up(xS, 1, Lp);
-    if (li == 0) xL = 0.0;
-    double x[M];
-    back_solve<M>(a, c, d, ip, xL, xS, x);
-    if (VEC) {
-        if (active && r0 < n) {
-            double2 *q = reinterpret_cast<double2 *>(out + base);
-#pragma unroll
-            for (int i = 0; i < M / 2; ++i) q[i] = make_double2(x[2 * i], x[2 * i + 1]);
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < M; ++r)
-            if (active && r0 + r < n) out[base + r] = x[r];
-    }
-}
-
-// GENERAL kernel: every unit (queue == nullptr) or the units a FAST kernel queued
-template <int M, bool VEC, bool HAS_DIR, bool HAS_Q>
-__global__ __launch_bounds__(256) void k_sweep_contig(
-    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
-    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    double *__restrict__ out, Lay L, int Lp, SweepScal s, long nunits, const unsigned *__restrict__ queue,
-    int ratio)
-{
-    // ratio: units of this kernel per queued unit (the FAST kernel may group more lines per wave)
-    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    if (queue == nullptr) {
-        const long unit = (long)blockIdx.x * wpb + wave;
-        if (unit < nunits)
-            contig_unit_general<M, VEC, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, Lp, s, unit);
-    } else {
-        const long cnt = (long)queue[0] * ratio;
-        for (long i = (long)blockIdx.x * wpb + wave; i < cnt; i += (long)gridDim.x * wpb) {
-            const long unit = (long)queue[1 + i / ratio] * ratio + (i % ratio);
-            if (unit < nunits)
-                contig_unit_general<M, VEC, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, Lp, s, unit);
-        }
-    }
-}
-
 // ---- coalesced global access for the contiguous FAST kernel ------------------------------------------------
 // A lane that loads its own M consecutive rows touches 64 different 128-byte lines per wave instruction; measured on
 // this part, pure streaming with 128-byte lane chunks tops out at 4.6-4.8 TB/s against 6.1 TB/s for fully
@@ -293,6 +205,109 @@ __device__ __forceinline__ void coal_store(double *__restrict__ gdst, double *st
             *reinterpret_cast<double2 *>(gdst + h * 32 * M + e) = t;
         }
         wave_lds_fence();
+    }
+}
+
+// GENERAL body for one wave-unit (unit = index of a group of 64/Lp consecutive lines)
+template <int M, bool VEC, bool HAS_DIR, bool HAS_Q, bool COAL>
+__device__ __forceinline__ void contig_unit_general(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ out, const Lay &L, int Lp, const SweepScal &s, long unit, double *strip)
+{
+    const int n = L.nz;
+    const long nlines = (long)L.nx * L.ny;
+    const int lane = threadIdx.x & 63;
+    const int lw = 64 / Lp;  // lines per wave
+    const int li = lane & (Lp - 1);
+    const long line = unit * lw + (lane / Lp);
+    const bool active = line < nlines;
+    const int r0 = li * M;
+    const long pi = line / L.ny;
+    const long base = pi * L.sx + (line - pi * L.ny) * (long)n + r0;
+
+    double vin[M], vco[M], vdv[M], vq[M];
+    unsigned fb[M], db[M];
+    load_bytes_contig<M, VEC>(flags, base, r0, n, active, fb);
+    if (HAS_DIR) load_bytes_contig<M, VEC>(dmask, base, r0, n, active, db);
+    const long wbase = __shfl(base, 0);    // COAL: the unit's lines are contiguous from lane 0's base
+    if constexpr (COAL) coal_load<M>(in + wbase, strip, lane, vin);
+    else load_rows_contig<M, VEC>(in, base, r0, n, active, vin);
+    if (COAL && !s.sparse) {               // dense packs: every lane needs every array -> cooperative loads
+        if constexpr (COAL) {
+            coal_load<M>(coeff + wbase, strip, lane, vco);
+            if (HAS_Q) coal_load<M>(qf + wbase, strip, lane, vq);
+            if (HAS_DIR) coal_load<M>(dval + wbase, strip, lane, vdv);
+        }
+    } else {
+        bool need = !s.sparse, needd = !s.sparse;
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            need = need || axis_exposed(fb[r], 5);
+            if (HAS_DIR) needd = needd || (db[r] != 0);
+        }
+        load_rows_contig<M, VEC>(coeff, base, r0, n, active && need, vco);
+        if (HAS_Q) load_rows_contig<M, VEC>(qf, base, r0, n, active && need, vq);
+        if (HAS_DIR) load_rows_contig<M, VEC>(dval, base, r0, n, active && needd, vdv);
+    }
+    double a[M], b[M], c[M], d[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r)   // flags: bit0 cell in mask, bit5 / bit6 the z- / z+ neighbour is in the mask
+        assemble_row<HAS_DIR, HAS_Q>(fb[r] & 1u, (fb[r] >> 5) & 1u, (fb[r] >> 6) & 1u, HAS_DIR && db[r] != 0, vin[r],
+                                     vco[r], HAS_DIR ? vdv[r] : 0.0, HAS_Q ? vq[r] : 0.0, s, a[r], b[r], c[r], d[r]);
+    double ip[M - 1];
+    Cond k;
+    condense<M>(a, b, c, d, ip, k);
+    // first-row data of the next segment of the same line
+    const double gFn = __shfl_down(k.gF, 1, Lp), aFn = __shfl_down(k.aF, 1, Lp), cFn = __shfl_down(k.cF, 1, Lp);
+    double ra, rb, rc, rd;
+    reduced_row(a[M - 1], b[M - 1], c[M - 1], d[M - 1], k, gFn, aFn, cFn, ra, rb, rc, rd);
+    const double xS = pcr_solve(ra, rb, rc, rd, li, Lp);
+    double xL = __shfl_up(xS, 1, Lp);
+    if (li == 0) xL = 0.0;
+    double x[M];
+    back_solve<M>(a, c, d, ip, xL, xS, x);
+    if constexpr (COAL) {
+        coal_store<M>(out + wbase, strip, lane, x);
+    } else if (VEC) {
+        if (active && r0 < n) {
+            double2 *q = reinterpret_cast<double2 *>(out + base);
+#pragma unroll
+            for (int i = 0; i < M / 2; ++i) q[i] = make_double2(x[2 * i], x[2 * i + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < M; ++r)
+            if (active && r0 + r < n) out[base + r] = x[r];
+    }
+}
+
+// GENERAL kernel: every unit (queue == nullptr) or the units a FAST kernel queued.
+// MODE: 0 scalar loads, 1 lane-chunk vector loads, 2 coalesced loads transposed through a wave-private LDS strip.
+template <int M, int MODE, bool HAS_DIR, bool HAS_Q>
+__global__ __launch_bounds__(256) void k_sweep_contig(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ out, Lay L, int Lp, SweepScal s, long nunits, const unsigned *__restrict__ queue,
+    int ratio)
+{
+    // ratio: units of this kernel per queued unit (the FAST kernel may group more lines per wave)
+    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    __shared__ __align__(16) double strips[MODE == 2 ? 4 * 32 * (M + 2) : 2];
+    double *strip = strips + (MODE == 2 ? wave * 32 * (M + 2) : 0);
+    if (queue == nullptr) {
+        const long unit = (long)blockIdx.x * wpb + wave;
+        if (unit < nunits)
+            contig_unit_general<M, MODE != 0, HAS_DIR, HAS_Q, MODE == 2>(in, flags, coeff, dmask, dval, qf, out, L, Lp, s,
+                                                                         unit, strip);
+    } else {
+        const long cnt = (long)queue[0] * ratio;
+        for (long i = (long)blockIdx.x * wpb + wave; i < cnt; i += (long)gridDim.x * wpb) {
+            const long unit = (long)queue[1 + i / ratio] * ratio + (i % ratio);
+            if (unit < nunits)
+                contig_unit_general<M, MODE != 0, HAS_DIR, HAS_Q, MODE == 2>(in, flags, coeff, dmask, dval, qf, out, L, Lp,
+                                                                             s, unit, strip);
+        }
     }
 }
 
@@ -1309,7 +1324,8 @@ static void launch_contig_fast(const double *in, const uint8_t *flags, const dou
     if (nocoal < 0) nocoal = getenv("ADI_NO_COAL") ? 1 : 0;
     const int lwf = 64 / Lpf;
     // coalesced + LDS-transposed access: whole units of contiguous lines (full last unit, no plane straddling)
-    const bool coal = vec && !nocoal && MF >= 4 && Lpf * MF == L.nz && (L.ny % lwf == 0);
+    const bool coal = vec && !nocoal && MF >= 4 && Lpf * MF == L.nz && (L.ny % lwf == 0) &&
+                      (((long)L.nx * L.ny) % lwf == 0);
     if (coal)
         hipLaunchKernelGGL((k_sweep_contig_fast<(MF >= 4 ? MF : 4), 2, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
                            dmask, dval, qf, out, L, Lpf, s, nunits_f, queue, make_unic<(MF >= 4 ? MF : 4)>(s.tg));
@@ -1352,11 +1368,17 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
         ggrid = grid < 2048u ? grid : 2048u;
     }
     const int ratio = fast ? lwf / lw : 1;
-    if (vec)
-        hipLaunchKernelGGL((k_sweep_contig<M, true, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(256), 0, st, in, flags, coeff,
+    static int nocoal = -1;
+    if (nocoal < 0) nocoal = getenv("ADI_NO_COAL") ? 1 : 0;
+    const bool coal = vec && !nocoal && M >= 4 && Lp * M == n && (L.ny % lw == 0) && (nlines % lw == 0);
+    if (coal)
+        hipLaunchKernelGGL((k_sweep_contig<(M >= 4 ? M : 4), 2, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(256), 0, st, in, flags,
+                           coeff, dmask, dval, qf, out, L, Lp, s, nunits, queue, ratio);
+    else if (vec)
+        hipLaunchKernelGGL((k_sweep_contig<M, 1, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(256), 0, st, in, flags, coeff,
                            dmask, dval, qf, out, L, Lp, s, nunits, queue, ratio);
     else
-        hipLaunchKernelGGL((k_sweep_contig<M, false, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(256), 0, st, in, flags, coeff,
+        hipLaunchKernelGGL((k_sweep_contig<M, 0, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(256), 0, st, in, flags, coeff,
                            dmask, dval, qf, out, L, Lp, s, nunits, queue, ratio);
 }
 
