@@ -218,13 +218,13 @@ __device__ __forceinline__ void contig_unit_general(
     const int n = L.nz;
     const long nlines = (long)L.nx * L.ny;
     const int lane = threadIdx.x & 63;
-    const int lw = 64 / Lp;  // lines per wave
+    const int lw = 64 >> (__ffs(Lp) - 1);  // lines per wave
     const int li = lane & (Lp - 1);
-    const long line = unit * lw + (lane / Lp);
-    const bool active = line < nlines;
+    const unsigned line = (unsigned)unit * (unsigned)lw + ((unsigned)lane >> (__ffs(Lp) - 1));   // < 2^31 lines
+    const bool active = line < (unsigned long)nlines;
     const int r0 = li * M;
-    const long pi = line / L.ny;
-    const long base = pi * L.sx + (line - pi * L.ny) * (long)n + r0;
+    const unsigned pi = line / (unsigned)L.ny;
+    const long base = (long)pi * L.sx + (long)(line - pi * (unsigned)L.ny) * n + r0;
 
     double vin[M], vco[M], vdv[M], vq[M];
     unsigned fb[M], db[M];
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_sweep_contig(
     } else {
         const long cnt = (long)queue[0] * ratio;
         for (long i = (long)blockIdx.x * wpb + wave; i < cnt; i += (long)gridDim.x * wpb) {
-            const long unit = (long)queue[1 + i / ratio] * ratio + (i % ratio);
+            const long unit = (long)queue[1 + i / ratio] * ratio + ((unsigned)i % (unsigned)ratio);
             if (unit < nunits)
                 contig_unit_general<M, MODE != 0, HAS_DIR, HAS_Q, MODE == 2>(in, flags, coeff, dmask, dval, qf, out, L, Lp,
                                                                              s, unit, strip);
@@ -324,15 +324,15 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     const int n = L.nz;
     const long nlines = (long)L.nx * L.ny;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long unit = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    const long unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + wave));
     if (unit >= nunits) return;
-    const int lw = 64 / Lp;
+    const int lw = 64 >> (__ffs(Lp) - 1);
     const int li = lane & (Lp - 1);
-    const long line = unit * lw + (lane / Lp);
-    const bool active = line < nlines;
+    const unsigned line = (unsigned)unit * (unsigned)lw + ((unsigned)lane >> (__ffs(Lp) - 1));   // < 2^31 lines
+    const bool active = line < (unsigned long)nlines;
     const int r0 = li * M;
-    const long pi = line / L.ny;
-    const long base = pi * L.sx + (line - pi * L.ny) * (long)n + r0;
+    const unsigned pi = line / (unsigned)L.ny;
+    const long base = (long)pi * L.sx + (long)(line - pi * (unsigned)L.ny) * n + r0;
 
     constexpr bool VEC = MODE != 0;
     __shared__ __align__(16) double strips[MODE == 2 ? 4 * 32 * (M + 2) : 2];
@@ -482,7 +482,7 @@ __device__ __forceinline__ void tile_separators(double *sm, int tid, int kk, int
     }
     __syncthreads();
     {
-        const int pl = tid / Lp, ps = tid - pl * Lp;  // line-major regrouping: Lp consecutive lanes = one line
+        const int pl = tid >> (__ffs(Lp) - 1), ps = tid & (Lp - 1);   // Lp is a power of two  // line-major regrouping: Lp consecutive lanes = one line
         const int w = pl * ld + ps;
         const double c2 = sCS[w];
         const bool hasn = ps < Lp - 1;
@@ -506,9 +506,9 @@ __device__ __forceinline__ void strided_tile_general(
     const double *__restrict__ xlo, const double *__restrict__ xhi, const SweepScal &s, double *sm)
 {
     const int tid = threadIdx.x;
-    const long to = tile / tiles_inner;
+    const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
     const int ti = (int)(tile - to * tiles_inner);
-    const int kk = tid % LINES, sg = tid / LINES;
+    const int kk = tid & (LINES - 1), sg = tid >> (__ffs(LINES) - 1);   // LINES is a power of two
     const int kcol = ti * LINES + kk;
     const bool active = kcol < g.n_inner;
     const long base = to * g.outer_stride + kcol;
@@ -562,9 +562,9 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
         // a queued unit is a tile of the FAST kernel = `ratio` adjacent tiles of this kernel
         const long cnt = (long)queue[0] * ratio;
         for (long i = blockIdx.x; i < cnt; i += gridDim.x) {
-            const long u = queue[1 + i / ratio];
-            const long to = u / tiles_inner_f;
-            const long tig = (u - to * tiles_inner_f) * ratio + (i % ratio);
+            const long u = queue[1 + (unsigned)i / (unsigned)ratio];
+            const long to = (long)((unsigned)u / (unsigned)tiles_inner_f);
+            const long tig = (u - to * tiles_inner_f) * ratio + ((unsigned)i % (unsigned)ratio);
             if (tig < tiles_inner)
                 strided_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, Lp, LINES, tiles_inner,
                                                         to * tiles_inner + tig, xlo, xhi, s, sm);
@@ -638,9 +638,9 @@ __global__ __launch_bounds__(512) void k_sweep_strided_fast(
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x;
     const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
-    const long to = tile / tiles_inner;
+    const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
     const int ti = (int)(tile - to * tiles_inner);
-    const int kk = tid % LINES, sg = tid / LINES;
+    const int kk = tid & (LINES - 1), sg = tid >> (__ffs(LINES) - 1);   // LINES is a power of two
     const int kcol = ti * LINES + kk;
     const bool active = kcol < g.n_inner;
     const long base = to * g.outer_stride + kcol;
@@ -700,7 +700,7 @@ __device__ __forceinline__ void tile_reduce_store(double *sm, int tid, int kk, i
         sm[3 * plane + w] = k.gL; sm[4 * plane + w] = k.aL; sm[5 * plane + w] = k.cL;
     }
     __syncthreads();
-    const int pl = tid / Lp, ps = tid - pl * Lp;
+    const int pl = tid >> (__ffs(Lp) - 1), ps = tid & (Lp - 1);   // Lp is a power of two
     const int w = pl * ld + ps;
     Cond q;
     q.gF = sm[w]; q.aF = sm[plane + w]; q.cF = sm[2 * plane + w];
@@ -722,9 +722,9 @@ __device__ __forceinline__ void condense_tile_general(
     const SweepScal &s, double *sm)
 {
     const int tid = threadIdx.x;
-    const long to = tile / tiles_inner;
+    const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
     const int ti = (int)(tile - to * tiles_inner);
-    const int kk = tid % LINES, sg = tid / LINES;
+    const int kk = tid & (LINES - 1), sg = tid >> (__ffs(LINES) - 1);   // LINES is a power of two
     const int kcol = ti * LINES + kk;
     const bool active = kcol < g.n_inner;
     const long base = to * g.outer_stride + kcol;
@@ -757,9 +757,9 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_condense_strided(
     } else {
         const long cnt = (long)queue[0] * ratio;
         for (long i = blockIdx.x; i < cnt; i += gridDim.x) {
-            const long u = queue[1 + i / ratio];
-            const long to = u / tiles_inner_f;
-            const long tig = (u - to * tiles_inner_f) * ratio + (i % ratio);
+            const long u = queue[1 + (unsigned)i / (unsigned)ratio];
+            const long to = (long)((unsigned)u / (unsigned)tiles_inner_f);
+            const long tig = (u - to * tiles_inner_f) * ratio + ((unsigned)i % (unsigned)ratio);
             if (tig < tiles_inner)
                 condense_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, LINES,
                                                          tiles_inner, to * tiles_inner + tig, s, sm);
@@ -780,9 +780,9 @@ __global__ __launch_bounds__(512) void k_condense_strided_fast(
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x;
     const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
-    const long to = tile / tiles_inner;
+    const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
     const int ti = (int)(tile - to * tiles_inner);
-    const int kk = tid % LINES, sg = tid / LINES;
+    const int kk = tid & (LINES - 1), sg = tid >> (__ffs(LINES) - 1);   // LINES is a power of two
     const int kcol = ti * LINES + kk;
     const bool active = kcol < g.n_inner;
     const long base = to * g.outer_stride + kcol;
@@ -977,11 +977,13 @@ __global__ __launch_bounds__(256) void k_explicit_v2(const double *__restrict__ 
     const int jc_per_slab = (jslab + kExplicitJR - 1) / kExplicitJR;
     const long per_plane = (long)jc_per_slab * ktiles;
     const long per_slab = per_plane * nx;
-    const int slab = (int)(tile / per_slab);
-    long rem = tile - (long)slab * per_slab;
-    const int i = (int)(rem / per_plane);
-    rem -= (long)i * per_plane;
-    const int jc = (int)(rem / ktiles), kt = (int)(rem - (long)jc * ktiles);
+    // block-uniform 32-bit arithmetic (64-bit divisions cost hundreds of scalar instructions per block)
+    const unsigned t32 = (unsigned)tile, pps = (unsigned)per_plane, psl = (unsigned)per_slab;
+    const int slab = (int)(t32 / psl);
+    unsigned rem = t32 - (unsigned)slab * psl;
+    const int i = (int)(rem / pps);
+    rem -= (unsigned)i * pps;
+    const int jc = (int)(rem / (unsigned)ktiles), kt = (int)(rem - (unsigned)jc * (unsigned)ktiles);
     const int jbeg = slab * jslab + jc * kExplicitJR;
     int jend = jbeg + kExplicitJR;
     if (jend > (slab + 1) * jslab) jend = (slab + 1) * jslab;
@@ -1055,11 +1057,12 @@ __global__ __launch_bounds__(256) void k_explicit_v3(const double *__restrict__ 
     const int nchunk = (nx + ichunk - 1) / ichunk;
     const long per_chunk = (long)jt_per_slab * ktiles;
     const long per_slab = per_chunk * nchunk;
-    const int slab = (int)(tile / per_slab);
-    long rem = tile - (long)slab * per_slab;
-    const int ic = (int)(rem / per_chunk);
-    rem -= (long)ic * per_chunk;
-    const int jt = (int)(rem / ktiles), kt = (int)(rem - (long)jt * ktiles);
+    const unsigned t32 = (unsigned)tile, pch = (unsigned)per_chunk, psl = (unsigned)per_slab;
+    const int slab = (int)(t32 / psl);
+    unsigned rem = t32 - (unsigned)slab * psl;
+    const int ic = (int)(rem / pch);
+    rem -= (unsigned)ic * pch;
+    const int jt = (int)(rem / (unsigned)ktiles), kt = (int)(rem - (unsigned)jt * (unsigned)ktiles);
     const int j0 = slab * jslab + jt * JT3;
     int jend = j0 + JT3;
     if (jend > (slab + 1) * jslab) jend = (slab + 1) * jslab;

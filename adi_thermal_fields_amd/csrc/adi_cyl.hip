@@ -65,9 +65,9 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_cyl_strided(
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x;
     const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
-    const long to = tile / tiles_inner;
+    const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
     const int ti = (int)(tile - to * tiles_inner);
-    const int kk = tid % LINES, sg = tid / LINES;
+    const int kk = tid & (LINES - 1), sg = tid >> (__ffs(LINES) - 1);   // LINES is a power of two
     const int kcol = ti * LINES + kk;
     const bool active = kcol < n_inner;
     const long base = to * outer_stride + kcol;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_cyl_strided(
     }
     __syncthreads();
     {
-        const int pl = tid / Lp, ps = tid - pl * Lp;
+        const int pl = tid >> (__ffs(Lp) - 1), ps = tid & (Lp - 1);   // Lp is a power of two
         const int w = pl * ld + ps;
         const double cS = sCS[w];
         const bool hasn = ps < Lp - 1;
@@ -174,13 +174,13 @@ __global__ __launch_bounds__(256) void k_cyl_contig(const double *__restrict__ i
                                                    double T_inner, long lines_per_r0, long sx)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lw = 64 / Lp;
+    const int lw = 64 >> (__ffs(Lp) - 1);
     const int li = lane & (Lp - 1);
-    const long line = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * lw + (lane / Lp);
-    const bool active = line < nlines;
+    const unsigned line = (blockIdx.x * (blockDim.x >> 6) + wave) * (unsigned)lw + ((unsigned)lane >> (__ffs(Lp) - 1));
+    const bool active = line < (unsigned long)nlines;
     const int r0 = li * M;
-    const long pi = line / lines_per_r0;   // radius index; lines_per_r0 = nphi
-    const long base = pi * sx + (line - pi * lines_per_r0) * (long)n + r0;
+    const unsigned pi = line / (unsigned)lines_per_r0;   // radius index; lines_per_r0 = nphi
+    const long base = (long)pi * sx + (long)(line - pi * (unsigned)lines_per_r0) * n + r0;
 
     double a[M], b[M], c[M], d[M];
     if (VEC) {
