@@ -1371,9 +1371,11 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
         ggrid = grid < 2048u ? grid : 2048u;
     }
     const int ratio = fast ? lwf / lw : 1;
-    static int nocoal = -1;
-    if (nocoal < 0) nocoal = getenv("ADI_NO_COAL") ? 1 : 0;
-    const bool coal = vec && !nocoal && M >= 4 && Lp * M == n && (L.ny % lw == 0) && (nlines % lw == 0);
+    // the GENERAL kernel gains nothing measurable from the LDS-transposed access (it is not bound by its access
+    // pattern at 100 VGPRs); kept behind ADI_GENERAL_COAL=1 for experiments
+    static int gcoal = -1;
+    if (gcoal < 0) gcoal = getenv("ADI_GENERAL_COAL") ? 1 : 0;
+    const bool coal = vec && gcoal && M >= 4 && Lp * M == n && (L.ny % lw == 0) && (nlines % lw == 0);
     if (coal)
         hipLaunchKernelGGL((k_sweep_contig<(M >= 4 ? M : 4), 2, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(256), 0, st, in, flags,
                            coeff, dmask, dval, qf, out, L, Lp, s, nunits, queue, ratio);
