@@ -267,6 +267,14 @@ class SlabStepper:
         self.packs_int = [interior_pack(p) for p in self.packs_ext]
         self.flags_int = _interior(self.flags_ext)
 
+    @staticmethod
+    def local_numpy(T):
+        """host copy of a local field in whatever form step() returned it"""
+        if isinstance(T, np.ndarray):
+            return T
+        t = T if isinstance(T, torch.Tensor) else T.t
+        return t.cpu().contiguous().numpy()
+
     # -- the step -----------------------------------------------------------------------------------
     def _load_state(self, T):
         """-> extended buffer whose interior holds T (no copy when T is the view step() returned)."""

@@ -168,3 +168,56 @@ def run_single_track(backend, plate_mask, track_box, dx, mat_args, h, Tinf, T_tr
             T = _step(backend, T, grid, mat, params, packs, Tinf)
         params.dt = dt_orig
     return np.asarray(T)
+
+
+def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, Ts, theta, cfl, layers, times_birth,
+                         times_out, engine=None, on_frame=None):
+    """The same event loop on ONE RANK of a slab decomposition (planes [i0, i1) of memory axis 0; BASELINE.json
+    configs[4] runs it on 4 GPUs).  Every rank knows the full host mask (bookkeeping only, 1 bit of information per
+    cell) and owns the temperature of its slab on its GPU; a birth is a masked fill of the local slab followed by
+    SlabStepper.set_mask (mask halo exchange + flags + pack rebuild).  Returns (local field as NumPy, steps)."""
+    from . import dist_slab
+    nx, ny, nz = mask_full.shape
+    mask_act = np.zeros_like(mask_full, dtype=bool)
+    params = params_cls(dt=1e-3, theta=theta)
+    alpha = mat.k / (mat.rho * mat.cp)
+    dt_cap = cfl * dx * dx / alpha
+    robin = {f: h for f in ('x-', 'x+', 'y-', 'y+', 'z-', 'z+')}
+    st = dist_slab.SlabStepper(mask_act[i0:i1], dx, mat, params, Tinf, robin_h=robin, comm=comm, engine=engine)
+    T = np.full((i1 - i0, ny, nz), float(Tinf), dtype=np.float64)
+    nsteps, next_birth, t_now = 0, 0, 0.0
+
+    def advance(seg):
+        nonlocal T, nsteps
+        nsub = max(1, int(math.ceil(seg / dt_cap)))
+        params.dt = max(seg / nsub, 1e-15)
+        for _ in range(nsub):
+            T = st.step(T)
+        nsteps += nsub
+
+    events = sorted(set(list(times_out) + list(times_birth)))
+    for te in events:
+        while next_birth < len(times_birth) and times_birth[next_birth] <= te + 1e-15:
+            t_b = times_birth[next_birth]
+            seg = max(0.0, t_b - t_now)
+            if seg > 1e-15 and mask_act.any():
+                advance(seg)
+            t_now = t_b
+            ks, ke = layers[next_birth]
+            born = np.zeros_like(mask_full, dtype=bool)
+            born[:, :, ks:ke + 1] = mask_full[:, :, ks:ke + 1]
+            newborn = (born & (~mask_act))[i0:i1]
+            if newborn.any():
+                Tl = np.array(st.local_numpy(T))
+                Tl[newborn] = Ts
+                T = Tl
+            mask_act |= born
+            st.set_mask(mask_act[i0:i1])
+            next_birth += 1
+        seg = max(0.0, te - t_now)
+        if seg > 1e-15 and mask_act.any():
+            advance(seg)
+        t_now = te
+        if on_frame is not None and any(abs(te - to) <= 1e-12 for to in times_out):
+            on_frame(t_now, np.array(st.local_numpy(T)), mask_act[i0:i1].copy())
+    return np.array(st.local_numpy(T)), nsteps

@@ -70,3 +70,38 @@ def test_single_track_hip_matches_oracle():
     want = waam.run_single_track(orc, *args)
     got = waam.run_single_track(hip, *args)
     assert rel_linf(got, want) <= 1e-10, rel_linf(got, want)
+
+
+@pytest.mark.gpu
+def test_layer_birth_on_slabs_matches_single_domain():
+    """configs[4] structure: layer birth on a slab decomposition (3 in-process ranks on one GPU, HIP engine) against
+    the single-domain HIP run of the same loop"""
+    import threading
+    import torch
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from adi_thermal_fields_amd import dist_slab
+    waam, mask, layers, dx, times = _setup((24, 24, 30))
+    outs = [0.0, times[-1]]
+    want, n1 = waam.run_layer_birth(hip, mask, dx, STEEL, 40.0, 20.0, 1000.0, 0.5, 2000.0, layers, times, outs)
+    world, sizes = 3, [8, 8, 8]
+    comms = dist_slab.LocalComm.make(world)
+    parts, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            torch.cuda.set_device(0)
+            i0 = sum(sizes[:rank]); i1 = i0 + sizes[rank]
+            parts[rank], _ = waam.run_layer_birth_slab(comms[rank], i0, i1, mask, dx, hip.Material(*STEEL), hip.Params,
+                                                       40.0, 20.0, 1000.0, 0.5, 2000.0, layers, times, outs)
+        except Exception as e:
+            errs.append(e)
+            comms[rank].sh.barrier.abort()
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    if errs:
+        raise errs[0]
+    got = np.concatenate(parts, axis=0)
+    assert rel_linf(got, want) <= 1e-11, rel_linf(got, want)
