@@ -36,7 +36,7 @@ from ._lib import lib, check, ptr_array, FACES
 
 __all__ = ['Grid3D', 'Material', 'Params', 'AxisCoeffPack', 'exposed_mask', 'precompute_coeff_packs_unified',
            'adi_step_hip_coeff', 'adi_step_numba_coeff', 'adi_step_gpu_coeff', 'DeviceField', 'to_device',
-           'adi_explicit_rhs', 'adi_sweep_axis', 'StagedStepper', 'Layout']
+           'adi_explicit_rhs', 'adi_sweep_axis', 'StagedStepper', 'Layout', 'apply_surface_impulse_Q']
 
 
 def _device():
@@ -482,6 +482,25 @@ def adi_step_hip_coeff(Tn, grid, mat, params, packs, Tinf=0.0):
     _sweep_into(1, tb, ta, grid, mat, params, packy, Tinf)
     _sweep_into(2, ta, out, grid, mat, params, packz, Tinf)
     return _wrap(out, kind)
+
+
+def apply_surface_impulse_Q(T, grid, mat, Q, face='z-'):
+    """adi3d_numba_coeff.py:304-320: add dT = Q/(rho cp dx) to the in-mask cells of the domain-boundary plane of
+    `face`, IN PLACE (NumPy array or DeviceField).  ValueError("bad face") for an unknown face."""
+    if face not in FACES:
+        raise ValueError("bad face")
+    dT = Q / (mat.rho * mat.cp * grid.dx)
+    ax, plus = FACES.index(face) // 2, FACES.index(face) % 2
+    sl = [slice(None)] * 3
+    sl[ax] = -1 if plus else 0
+    sl = tuple(sl)
+    if isinstance(T, DeviceField):
+        sel = (grid.d_mask[sl] != 0)
+        plane = T.t[sl]
+        plane[sel] = plane[sel] + dT
+    else:
+        sel = np.asarray(grid.mask)[sl]
+        T[sl][sel] += dT
 
 
 # the reference's backend-specific names, so its drivers run unchanged on this module

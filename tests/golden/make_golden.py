@@ -87,6 +87,11 @@ def run_cart(name, stages=False, planes_only=False):
             cur = sw[ax](T, cur, grid.mask, p.coeff, p.dir_mask, p.dir_val, p.qflux, prm.theta, gam, prm.dt,
                          kappa, c['Tinf'])
             out[nm] = cur
+    if name == 'edge_shapes' or name == 'kat2':   # apply_surface_impulse_Q (adi3d_numba_coeff.py:304-320), in place
+        for f in cases.FACES:
+            Ti = np.array(c['T0'], dtype=np.float64)
+            ref.apply_surface_impulse_Q(Ti, grid, mat, 3.5e4, face=f)
+            out['impulse_' + f] = Ti
     if c['births'] is None:
         for s in range(c['nsteps']):
             T = ref.adi_step_numba_coeff(T, grid, mat, prm, packs, Tinf=c['Tinf'])

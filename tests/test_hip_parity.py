@@ -175,3 +175,39 @@ def test_random_shapes_and_bcs(hip):
         worst = max(worst, err)
         assert err <= TOL, (shape, kind, err)
     print('worst rel_linf over random cases: %.3e' % worst)
+
+
+@pytest.mark.parametrize('name', ['kat2', 'edge_shapes'])
+def test_surface_impulse(hip, name):
+    """apply_surface_impulse_Q (adi3d_numba_coeff.py:304-320), host array and device field, in place"""
+    c = cases.cart_case(name)
+    g = golden('cart', name)
+    grid = hip.Grid3D(*c['shape'], c['dx'], c['mask']); mat = hip.Material(**c['mat'])
+    for f in cases.FACES:
+        T = np.array(c['T0'], dtype=np.float64)
+        hip.apply_surface_impulse_Q(T, grid, mat, 3.5e4, face=f)
+        assert np.array_equal(T, g['impulse_' + f]), f
+        D = hip.to_device(c['T0'])
+        hip.apply_surface_impulse_Q(D, grid, mat, 3.5e4, face=f)
+        assert np.array_equal(D.get(), g['impulse_' + f]), f
+    with pytest.raises(ValueError):
+        hip.apply_surface_impulse_Q(np.zeros(c['shape']), grid, mat, 1.0, face='q')
+
+
+def test_device_field_ndarray_surface(hip):
+    """the slice of the ndarray surface the reference's drivers use on their temperature field"""
+    rng = np.random.default_rng(1)
+    A = rng.uniform(0, 100, (6, 5, 8))
+    D = hip.to_device(A)
+    assert D.shape == (6, 5, 8) and D.ndim == 3 and D.size == 240
+    assert np.array_equal(np.asarray(D), A) and np.array_equal(D.get(), A)
+    assert np.array_equal(D[2, 3, :], A[2, 3, :]) and D[1, 2, 3] == A[1, 2, 3]
+    assert D.min() == A.min() and D.max() == A.max() and abs(D.sum() - A.sum()) < 1e-9
+    idx = np.where(A > 90.0)
+    D[idx] = 7.0; A[idx] = 7.0                       # T[idx] = Ts        (waam_from_stl_v7_mm.py:489-493)
+    D[1:3, 0:1, 2:5] = 3.0; A[1:3, 0:1, 2:5] = 3.0   # T[x0:x1, yi:yi+1, z0:z1] = T_track_init (single_track_on_plate.py:166)
+    E = D.copy(); E[...] = D                         # T[...] = step(...)  (single_track_on_plate.py:175)
+    assert np.array_equal(E.get(), A)
+    m = A > 50.0
+    D[m] = 1.0; A[m] = 1.0
+    assert np.array_equal(D.get(), A)

@@ -137,3 +137,14 @@ def test_cyl_bad_zbc_kind():
     c['zbc'] = dict(kind_bot='bogus', kind_top='robin')
     with pytest.raises(ValueError):
         run_cyl_case(cyl, c)
+
+
+@pytest.mark.parametrize('name', ['kat2', 'edge_shapes'])
+def test_surface_impulse_oracle(name):
+    c = cases.cart_case(name)
+    g = golden('cart', name)
+    grid = orc.Grid3D(*c['shape'], c['dx'], c['mask']); mat = orc.Material(**c['mat'])
+    for f in cases.FACES:
+        T = np.array(c['T0'], dtype=np.float64)
+        orc.apply_surface_impulse_Q(T, grid, mat, 3.5e4, face=f)
+        assert np.array_equal(T, g['impulse_' + f]), f
