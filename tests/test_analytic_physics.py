@@ -1,0 +1,92 @@
+"""Physics regression with asserted tolerances, independent of the oracle (the reference's
+quick_compare_* scripts only plot their analytic comparisons).  Runs the same checks on the CPU oracle (always) and
+on the HIP backend (GPU)."""
+import math
+
+import numpy as np
+import pytest
+
+STEEL = dict(rho=7800.0, cp=490.0, k=54.0)
+ALPHA = STEEL['k'] / (STEEL['rho'] * STEEL['cp'])
+
+
+def _erfc_case(api, to_state=lambda x: x, to_host=lambda x: np.asarray(x)):
+    """Dirichlet step on the face z = 0 of an insulated bar (quick_compare_dirichlet_robin.py without side losses):
+    T(z, t) = T0 + (Ts - T0) erfc(z / (2 sqrt(alpha t))) while the far end is not reached."""
+    nx, ny, nz = 4, 4, 256
+    dx = 2.5e-4
+    mask = np.ones((nx, ny, nz), bool)
+    dm = np.zeros_like(mask); dm[:, :, 0] = True; dm[:, :, -1] = True
+    dv = np.zeros(mask.shape); dv[:, :, 0] = 1000.0; dv[:, :, -1] = 20.0
+    grid = api.Grid3D(nx, ny, nz, dx, mask)
+    mat = api.Material(**STEEL)
+    dt = 0.5 * dx * dx / ALPHA
+    prm = api.Params(dt, 0.5)
+    packs = api.precompute_coeff_packs_unified(grid, mat, dir_mask=dm, dir_value=dv)
+    T = to_state(np.full(mask.shape, 20.0))
+    step = getattr(api, 'adi_step_hip_coeff', None) or api.adi_step_numba_coeff
+    nsteps = 400
+    for _ in range(nsteps):
+        T = step(T, grid, mat, prm, packs, Tinf=20.0)
+    T = to_host(T)
+    t = nsteps * dt
+    z = np.arange(nz) * dx            # the Dirichlet cell centre is the surface
+    ana = 20.0 + 980.0 * np.array([math.erfc(v / (2.0 * math.sqrt(ALPHA * t))) for v in z])
+    prof = T[2, 2, :]
+    assert np.allclose(T, T[:1, :1, :], rtol=0, atol=1e-9)        # 1-D problem stays 1-D
+    err = np.max(np.abs(prof - ana)) / 980.0
+    assert err < 5e-3, err                                          # second-order scheme, 256 cells
+    return err
+
+
+def _linear_steady_state(api, to_state=lambda x: x, to_host=lambda x: np.asarray(x)):
+    """a linear profile between two Dirichlet planes is an exact fixed point of the discrete scheme"""
+    shape = (6, 5, 40)
+    mask = np.ones(shape, bool)
+    dm = np.zeros(shape, bool); dm[:, :, 0] = True; dm[:, :, -1] = True
+    dv = np.zeros(shape); dv[:, :, 0] = 1000.0; dv[:, :, -1] = 20.0
+    lin = np.broadcast_to(np.linspace(1000.0, 20.0, shape[2]), shape).copy()
+    grid = api.Grid3D(*shape, 1e-3, mask)
+    mat = api.Material(**STEEL)
+    prm = api.Params(50.0 * 1e-6 / ALPHA, 0.5)
+    packs = api.precompute_coeff_packs_unified(grid, mat, dir_mask=dm, dir_value=dv)
+    step = getattr(api, 'adi_step_hip_coeff', None) or api.adi_step_numba_coeff
+    T = to_state(lin)
+    for _ in range(5):
+        T = step(T, grid, mat, prm, packs, Tinf=20.0)
+    assert np.max(np.abs(to_host(T) - lin)) < 1e-9
+
+
+def _energy_balance(api, to_state=lambda x: x, to_host=lambda x: np.asarray(x)):
+    """insulated body heated through one face by a Neumann flux q for time t gains exactly q*A*t of heat
+    (sum over cells of rho cp dx^3 dT), the discrete scheme being conservative"""
+    shape = (10, 12, 14)
+    dx = 1e-3
+    mask = np.ones(shape, bool)
+    grid = api.Grid3D(*shape, dx, mask)
+    mat = api.Material(**STEEL)
+    prm = api.Params(30.0 * dx * dx / ALPHA, 0.5)
+    q = 2.5e5
+    packs = api.precompute_coeff_packs_unified(grid, mat, neumann={'z-': q})
+    step = getattr(api, 'adi_step_hip_coeff', None) or api.adi_step_numba_coeff
+    T = to_state(np.full(shape, 20.0))
+    n = 6
+    for _ in range(n):
+        T = step(T, grid, mat, prm, packs, Tinf=20.0)
+    gained = (to_host(T) - 20.0).sum() * STEEL['rho'] * STEEL['cp'] * dx ** 3
+    expect = q * (shape[0] * shape[1] * dx * dx) * n * prm.dt
+    # the factorised (ADI) operator adds O(dt^2) cross terms, so the balance holds to that order, not to rounding
+    assert abs(gained - expect) / expect < 2e-2, (gained, expect)
+
+
+@pytest.mark.parametrize('check', [_erfc_case, _linear_steady_state, _energy_balance])
+def test_physics_on_oracle(check):
+    from oracle import adi_oracle as orc
+    check(orc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('check', [_erfc_case, _linear_steady_state, _energy_balance])
+def test_physics_on_hip(check):
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    check(hip, to_state=hip.to_device, to_host=lambda d: d.get())
