@@ -211,3 +211,24 @@ def test_device_field_ndarray_surface(hip):
     m = A > 50.0
     D[m] = 1.0; A[m] = 1.0
     assert np.array_equal(D.get(), A)
+
+
+@pytest.mark.parametrize('shape', [(768, 3, 16), (3, 1024, 8), (4, 6, 1024), (1500, 2, 8), (2, 1300, 4), (3, 2, 2050)])
+def test_very_long_lines(hip, shape):
+    """513..1024 rows: 16 rows per thread; beyond 1024: the generic one-thread-per-line kernel with HBM scratch"""
+    from oracle import adi_oracle as orc
+    rng = np.random.default_rng(shape[0] + shape[2])
+    mask = rng.random(shape) > 0.03
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,
+             T0=rng.uniform(20.0, 1200.0, shape), dir_mask=None, dir_value=None,
+             neumann={'x+': 1e5}, robin_h={'x-': 300.0, 'y-': 200.0, 'z+': 500.0, 'z-': 100.0}, Tinf=20.0, theta=0.5,
+             dt=400.0 * dx * dx / alpha, nsteps=2, births=None)
+    got = run_cart_case(hip, c)['T_final']
+    want = run_cart_case(orc, c)['T_final']
+    assert rel_linf(got, want) <= TOL, rel_linf(got, want)
+    c2 = dict(c, neumann=None, mask=np.ones(shape, bool))        # solid block: FAST kernels with 16 rows per thread
+    got = run_cart_case(hip, c2)['T_final']
+    want = run_cart_case(orc, c2)['T_final']
+    assert rel_linf(got, want) <= TOL, rel_linf(got, want)
