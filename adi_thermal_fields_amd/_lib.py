@@ -46,6 +46,8 @@ SIGNATURES = {
     'adi_build_nbr_flags': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p]),
     'adi_explicit_rhs': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_double, c_double, c_double,
                                  c_double, c_void_p, c_void_p]),
+    'adi_explicit_rhs_planes': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_double, c_double, c_double,
+                                        c_double, c_void_p, c_int, c_int, c_void_p]),
     'adi_sweep': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

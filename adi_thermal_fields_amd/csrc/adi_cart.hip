@@ -1047,14 +1047,15 @@ constexpr int JT3 = 4;
 
 __global__ __launch_bounds__(256) void k_explicit_v3(const double *__restrict__ T, const uint8_t *__restrict__ flags,
                                                      double *__restrict__ R0, Lay L, double invdx2, double f,
-                                                     int jslab, int ktiles, int ichunk, long ntiles)
+                                                     int jslab, int ktiles, int ichunk, long ntiles, int i_begin,
+                                                     int i_end)
 {
 #pragma clang fp contract(off)
     const int nx = L.nx, ny = L.ny, nz = L.nz;
     const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
     // tile order: [slab][i-chunk][j-tile in slab][k-tile]
     const int jt_per_slab = (jslab + JT3 - 1) / JT3;
-    const int nchunk = (nx + ichunk - 1) / ichunk;
+    const int nchunk = (i_end - i_begin + ichunk - 1) / ichunk;
     const long per_chunk = (long)jt_per_slab * ktiles;
     const long per_slab = per_chunk * nchunk;
     const unsigned t32 = (unsigned)tile, pch = (unsigned)per_chunk, psl = (unsigned)per_slab;
@@ -1068,8 +1069,8 @@ __global__ __launch_bounds__(256) void k_explicit_v3(const double *__restrict__ 
     if (jend > (slab + 1) * jslab) jend = (slab + 1) * jslab;
     if (jend > ny) jend = ny;
     if (j0 >= jend) return;
-    const int i0 = ic * ichunk;
-    const int i1 = (i0 + ichunk < nx) ? i0 + ichunk : nx;
+    const int i0 = i_begin + ic * ichunk;
+    const int i1 = (i0 + ichunk < i_end) ? i0 + ichunk : i_end;
     const int k0 = kt * 512 + 2 * (int)threadIdx.x;
     const bool kin = k0 < nz;
     const int lane = threadIdx.x & 63;
@@ -1152,12 +1153,15 @@ __device__ __forceinline__ bool cell_of(long q, const Lay &L, int &i, int &j, in
 
 // generic form (odd nz or unaligned views): one cell per thread
 __global__ __launch_bounds__(256) void k_explicit(const double *__restrict__ T, const uint8_t *__restrict__ flags,
-                                                  double *__restrict__ R0, Lay L, double invdx2, double f)
+                                                  double *__restrict__ R0, Lay L, double invdx2, double f, int i_begin,
+                                                  int i_end)
 {
 #pragma clang fp contract(off)
     int i, j, k;
     long p;
-    if (!cell_of((long)blockIdx.x * blockDim.x + threadIdx.x, L, i, j, k, p)) return;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x + (long)i_begin * L.ny * L.nz;
+    if (q >= (long)i_end * L.ny * L.nz) return;
+    if (!cell_of(q, L, i, j, k, p)) return;
     const long sx = L.sx, sy = L.nz;
     const double t = T[p];
     const unsigned fl = flags[p];
@@ -1653,42 +1657,55 @@ int adi_build_nbr_flags(const uint8_t *d_mask, int nx, int ny, int nz, long plan
     return ADI_OK;
 }
 
-int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride, double dx,
-                     double dt, double kappa, double theta, double *d_R0, void *stream)
+int adi_explicit_rhs_planes(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride,
+                            double dx, double dt, double kappa, double theta, double *d_R0, int i_begin, int i_end,
+                            void *stream)
 {
     ADI_REQUIRE(d_T && d_flags && d_R0, "adi_explicit_rhs: null argument");
     ADI_REQUIRE(d_T != d_R0, "adi_explicit_rhs: output aliases input");
     Lay L;
     if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    ADI_REQUIRE(i_begin >= 0 && i_end <= nx && i_begin <= i_end, "adi_explicit_rhs_planes: bad plane range [%d, %d)",
+                i_begin, i_end);
+    if (i_begin == i_end) return ADI_OK;
     const double invdx2 = 1.0 / (dx * dx);
     const double f = dt * kappa * (1.0 - theta);
+    const int np = i_end - i_begin;
     const bool fast = (nz % 2 == 0) && (L.sx % 2 == 0) && ((((uintptr_t)d_T | (uintptr_t)d_R0) & 15) == 0) &&
                       (((uintptr_t)d_flags & 1) == 0);
-    if (fast) {
+    static int ver = 0;
+    if (ver == 0) { const char *e = getenv("ADI_EXPLICIT_VER"); ver = e ? atoi(e) : 3; }
+    if (fast && (ver == 3 || np != nx)) {
         const int jslab = (ny + 7) / 8;
         const int nslab = (ny + jslab - 1) / jslab;
         const int ktiles = (nz + 511) / 512;
-        static int ver = 0;
-        if (ver == 0) { const char *e = getenv("ADI_EXPLICIT_VER"); ver = e ? atoi(e) : 3; }
-        if (ver == 3) {
-            int ichunk = 32;
-            { const char *e = getenv("ADI_EXPLICIT_ICHUNK"); if (e) ichunk = atoi(e); if (ichunk < 1) ichunk = 32; }
-            const int nchunk = (nx + ichunk - 1) / ichunk;
-            const long ntiles = (long)nslab * nchunk * ((jslab + JT3 - 1) / JT3) * ktiles;
-            hipLaunchKernelGGL(k_explicit_v3, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
-                               L, invdx2, f, jslab, ktiles, ichunk, ntiles);
-        } else {
-            const int kExplicitJR = explicit_jr();
-            const long ntiles = (long)nslab * nx * ((jslab + kExplicitJR - 1) / kExplicitJR) * ktiles;
-            hipLaunchKernelGGL(k_explicit_v2, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
-                               L, invdx2, f, jslab, ktiles, ntiles, kExplicitJR);
-        }
+        int ichunk = 32;
+        { const char *e = getenv("ADI_EXPLICIT_ICHUNK"); if (e) ichunk = atoi(e); if (ichunk < 1) ichunk = 32; }
+        const int nchunk = (np + ichunk - 1) / ichunk;
+        const long ntiles = (long)nslab * nchunk * ((jslab + JT3 - 1) / JT3) * ktiles;
+        hipLaunchKernelGGL(k_explicit_v3, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0, L,
+                           invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end);
+    } else if (fast) {
+        const int jslab = (ny + 7) / 8;
+        const int nslab = (ny + jslab - 1) / jslab;
+        const int ktiles = (nz + 511) / 512;
+        const int kExplicitJR = explicit_jr();
+        const long ntiles = (long)nslab * nx * ((jslab + kExplicitJR - 1) / kExplicitJR) * ktiles;
+        hipLaunchKernelGGL(k_explicit_v2, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0, L,
+                           invdx2, f, jslab, ktiles, ntiles, kExplicitJR);
     } else {
-        hipLaunchKernelGGL(k_explicit, dim3(cell_blocks(L)), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0, L,
-                           invdx2, f);
+        const long cells = (long)np * ny * nz;
+        hipLaunchKernelGGL(k_explicit, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, as_stream(stream), d_T,
+                           d_flags, d_R0, L, invdx2, f, i_begin, i_end);
     }
     ADI_CHECK_LAUNCH();
     return ADI_OK;
+}
+
+int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride, double dx,
+                     double dt, double kappa, double theta, double *d_R0, void *stream)
+{
+    return adi_explicit_rhs_planes(d_T, d_flags, nx, ny, nz, plane_stride, dx, dt, kappa, theta, d_R0, 0, nx, stream);
 }
 
 int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, long plane_stride, size_t *bytes)

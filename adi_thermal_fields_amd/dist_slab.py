@@ -147,10 +147,11 @@ class HipEngine:
         return self.hip.precompute_coeff_packs_unified(g, mat, dir_mask=dir_mask, dir_value=dir_value,
                                                        neumann=neumann, robin_h=robin_h)
 
-    def explicit(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext):
+    def explicit(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin=0, i_end=None):
         h = self.hip
-        self.check(self.lib.adi_explicit_rhs(h._p(T_ext), h._p(flags_ext), L.nx, L.ny, L.nz, L.sx, dx, dt, kappa,
-                                             theta, h._p(out_ext), h._stream()))
+        i_end = L.nx if i_end is None else i_end
+        self.check(self.lib.adi_explicit_rhs_planes(h._p(T_ext), h._p(flags_ext), L.nx, L.ny, L.nz, L.sx, dx, dt, kappa,
+                                                    theta, h._p(out_ext), i_begin, i_end, h._stream()))
 
     def _args(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf):
         h = self.hip
@@ -371,10 +372,32 @@ class SlabStepper:
                 events[i].record()
         mark(0)
         # 1. state halos (zeros outside the global grid are never read: the flags carry no coupling there)
+        # 2. explicit stage: the planes that do not touch a halo run while the halo planes are in flight
         lo = Text[0]; hi = Text[-1]
-        self.comm.exchange_planes(Text[1], Text[-2], lo, hi)
-        # 2. explicit stage on the extended slab
-        E.explicit(self.Lext, Text, self.flags_ext, self.dx, prm.dt, kappa, prm.theta, A)
+        self._chunks()
+        nl = self.nxl
+        overlap = self._use_streams and self.world > 1
+        ev1 = None
+        if overlap:
+            main = torch.cuda.current_stream()
+            ev0 = torch.cuda.Event(); ev0.record(main)
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ev0)                       # Text is complete
+                self.comm.exchange_planes(Text[1], Text[-2], lo, hi)
+                ev1 = torch.cuda.Event(); ev1.record(self._comm_stream)
+        else:
+            self.comm.exchange_planes(Text[1], Text[-2], lo, hi)
+        ex = lambda b, e: E.explicit(self.Lext, Text, self.flags_ext, self.dx, prm.dt, kappa, prm.theta, A, b, e)
+        if self.world > 1 and nl >= 4:
+            ex(2, nl)                        # planes that touch no halo
+            if ev1 is not None:
+                main.wait_event(ev1)
+            ex(1, 2)                         # first and last local plane need the neighbours' planes
+            ex(nl, nl + 1)
+        else:
+            if ev1 is not None:
+                main.wait_event(ev1)
+            ex(1, nl + 1)
         mark(1)
         Ai, Bi, Oi = _interior(A), _interior(B), _interior(nxt)
         v, Li, fl = self.variant, self.Lint, self.flags_int

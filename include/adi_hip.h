@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 4
+#define ADI_ABI_VERSION 5
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -99,6 +99,11 @@ int adi_build_nbr_flags(const uint8_t *d_mask, int nx, int ny, int nz, long plan
 /* lap1D_x/y/z + R0 = Tn + dt*kappa*(1-theta)*(Lx+Ly+Lz): adi3d_numba_coeff.py:240-288, :298 */
 int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride,
                      double dx, double dt, double kappa, double theta, double *d_R0, void *stream);
+/* the same for planes [i_begin, i_end) of the array only (neighbour planes are still read where they exist): lets a
+ * slab compute its interior planes while the halo planes are in flight */
+int adi_explicit_rhs_planes(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride,
+                            double dx, double dt, double kappa, double theta, double *d_R0,
+                            int i_begin, int i_end, void *stream);
 
 /*
  * sweep_axis0/1/2: adi3d_numba_coeff.py:133-237 (full-length identity-row form of

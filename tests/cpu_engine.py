@@ -94,7 +94,7 @@ class CpuEngine:
         t = torch.from_numpy
         return tuple(_Pack(t(p.coeff), t(p.dir_mask.view(np.uint8)), t(p.dir_val), t(p.qflux), variant) for p in packs)
 
-    def explicit(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext):
+    def explicit(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin=0, i_end=None):
         mask = (flags_ext.numpy() & 1).astype(bool)
         grid = orc.Grid3D(L.nx, L.ny, L.nz, dx, mask)
         out_ext.copy_(torch.from_numpy(orc.explicit_rhs(np.nan_to_num(T_ext.numpy()), grid, orc.Material(1.0, 1.0, kappa),
