@@ -1606,7 +1606,9 @@ long adi_recommended_plane_stride(int ny, int nz)
     // planes whose byte size is a multiple of 16 KiB alias on the HBM channel interleave when walked with
     // that stride (axis-0 sweeps): pad by 512 elements (4 KiB keeps every plane 4 KiB-aligned).
     const long dense = (long)ny * nz;
-    return (dense * 8 % 16384 == 0) ? dense + 512 : dense;
+    static long pad = -1;
+    if (pad < 0) { const char *e = getenv("ADI_PLANE_PAD"); pad = e ? atol(e) : 512; if (pad < 0 || pad % 2) pad = 512; }
+    return (dense * 8 % 16384 == 0) ? dense + pad : dense;
 }
 
 int adi_exposed_mask(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, int face, uint8_t *d_exposed,
