@@ -896,6 +896,33 @@ __global__ __launch_bounds__(256) void k_interface(const double *__restrict__ co
     xhi[id] = S.gF - S.aF * l;
 }
 
+// Neighbour-only form of the interface system, valid when the far-side couplings of the boundary windows
+// (aL of the window that ends a slab, cF of the window that starts one) have decayed below rounding:
+//   x_last(r)    = gL  - cL  * x_first(r+1)        (window = last rows of slab r)
+//   x_first(r+1) = gF' - aF' * x_last(r)           (window = first rows of slab r+1)
+// my_lo / my_hi: [6][nlines] condensations of this slab's first / last window; prev_hi: rows (gL,aL,cL) of the
+// slab below; next_lo: rows (gF,aF) of the slab above.  NULL neighbour -> 0.
+__global__ __launch_bounds__(256) void k_interface_pair(const double *__restrict__ my_lo, const double *__restrict__ my_hi,
+                                                        const double *__restrict__ prev_hi, const double *__restrict__ next_lo,
+                                                        long nlines, double *__restrict__ xlo, double *__restrict__ xhi)
+{
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nlines) return;
+    double lo = 0.0, hi = 0.0;
+    if (prev_hi) {
+        const double gLp = prev_hi[id], cLp = prev_hi[2 * nlines + id];
+        const double gF = my_lo[id], aF = my_lo[nlines + id];
+        lo = (gLp - cLp * gF) / (1.0 - cLp * aF);
+    }
+    if (next_lo) {
+        const double gFn = next_lo[id], aFn = next_lo[nlines + id];
+        const double gL = my_hi[3 * nlines + id], cL = my_hi[5 * nlines + id];
+        hi = (gFn - aFn * gL) / (1.0 - aFn * cL);
+    }
+    xlo[id] = lo;
+    xhi[id] = hi;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: generic fallback, one thread per line, normalised Thomas (adi3d_gpu_coeff.py:140-152) with the
 // forward-pass c', d' kept in an HBM workspace.  Used only for lines longer than kMaxFastLine rows.
@@ -1604,10 +1631,10 @@ extern "C" {
 long adi_recommended_plane_stride(int ny, int nz)
 {
     // planes whose byte size is a multiple of 16 KiB alias on the HBM channel interleave when walked with
-    // that stride (axis-0 sweeps): pad by 512 elements (4 KiB keeps every plane 4 KiB-aligned).
+    // that stride (axis-0 sweeps): pad by 256 elements (2 KiB; a sweep over 64..4608 showed 256 a few percent ahead on the axis-0 sweep).
     const long dense = (long)ny * nz;
     static long pad = -1;
-    if (pad < 0) { const char *e = getenv("ADI_PLANE_PAD"); pad = e ? atol(e) : 512; if (pad < 0 || pad % 2) pad = 512; }
+    if (pad < 0) { const char *e = getenv("ADI_PLANE_PAD"); pad = e ? atol(e) : 256; if (pad < 0 || pad % 8) pad = 256; }
     return (dense * 8 % 16384 == 0) ? dense + pad : dense;
 }
 
@@ -1681,8 +1708,10 @@ int adi_explicit_rhs_planes(const double *d_T, const uint8_t *d_flags, int nx, i
         const int jslab = (ny + 7) / 8;
         const int nslab = (ny + jslab - 1) / jslab;
         const int ktiles = (nz + 511) / 512;
-        int ichunk = 32;
-        { const char *e = getenv("ADI_EXPLICIT_ICHUNK"); if (e) ichunk = atoi(e); if (ichunk < 1) ichunk = 32; }
+        // planes marched per block: 32 amortises the leading halo plane; short plane ranges (the boundary windows of a
+        // slab) get shorter chunks so that the launch still has ~16 chunks' worth of blocks
+        int ichunk = np >= 512 ? 32 : (np / 16 < 4 ? 4 : np / 16);
+        { const char *e = getenv("ADI_EXPLICIT_ICHUNK"); if (e && atoi(e) >= 1) ichunk = atoi(e); }
         const int nchunk = (np + ichunk - 1) / ichunk;
         const long ntiles = (long)nslab * nchunk * ((jslab + JT3 - 1) / JT3) * ktiles;
         hipLaunchKernelGGL(k_explicit_v3, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0, L,
@@ -1795,6 +1824,17 @@ int adi_interface_solve(const double *d_cond_all, int nranks, int rank, long nli
                 "adi_interface_solve: bad argument");
     hipLaunchKernelGGL(k_interface, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, as_stream(stream), d_cond_all,
                        nranks, rank, nlines, d_xlo, d_xhi);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+int adi_interface_pair(const double *d_my_lo, const double *d_my_hi, const double *d_prev_hi, const double *d_next_lo,
+                       long nlines, double *d_xlo, double *d_xhi, void *stream)
+{
+    ADI_REQUIRE(d_xlo && d_xhi && nlines > 0, "adi_interface_pair: bad argument");
+    ADI_REQUIRE((!d_prev_hi || d_my_lo) && (!d_next_lo || d_my_hi), "adi_interface_pair: missing own window");
+    hipLaunchKernelGGL(k_interface_pair, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, as_stream(stream), d_my_lo,
+                       d_my_hi, d_prev_hi, d_next_lo, nlines, d_xlo, d_xhi);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }

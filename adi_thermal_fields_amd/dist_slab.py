@@ -8,12 +8,22 @@ Per step and rank (nxl local planes, halo planes at both ends of every extended 
      the mask halo travels only when the mask changes (pack rebuild).
   2. explicit stage on the extended slab (interior result used).
   3. axis-0 sweep, whose lines span all ranks, as a reduced-interface solve:
-       pass A  adi_sweep_condense: every local line -> 6 numbers (first/last unknown as affine functions of
-               the neighbours' adjacent unknowns),
-       all_gather of the (6, ny*nz) block (12.6 MB per rank at 512^2),
-       adi_interface_solve: each rank merges the slabs below/above it and solves a 2x2 system per line,
+       pass A  adi_sweep_condense: rows of every local line -> 6 numbers (first/last unknown as affine functions
+               of the neighbours' adjacent unknowns),
+       exchange + interface solve -> the two boundary values of every line,
        pass B  adi_sweep with the boundary values injected: the ordinary local sweep.
-     Exact (not iterative): the result equals the single-domain sweep to rounding.
+     Two forms of the middle step, chosen per (dt, theta, mask) by looking at the condensed matrix entries:
+       neighbour-only ("windowed"): the coupling of a slab's last unknown to the unknown BEFORE the slab (aL), and
+               of its first unknown to the one AFTER it (cF), decays like rho^rows (rho < 1 from diagonal
+               dominance).  When both are <= 1e-17 on every line -- below the rounding of the data they would
+               multiply -- the interface system splits into independent 2x2 systems between neighbours:
+               send (gF,aF) down and (gL,aL,cL) up (send/recv, 6.3 + 4.2 MB at 512^2), adi_interface_pair.
+               When the decay length K is below half the slab, pass A runs only on the first and last K planes
+               (the same argument applied to the window) and its exchange hides behind the explicit stage of
+               the middle planes.
+       exact:  all_gather of the (6, ny*nz) block (12.6 MB per rank at 512^2) + adi_interface_solve (each rank
+               merges the slabs below/above it and solves a 2x2 system per line); thin slabs / huge dt.
+     Either way the result equals the single-domain sweep to rounding.
   4. axis-1 and axis-2 sweeps: lines are local, no communication.
 
 The numerical work is behind an `engine` (HIP kernels through the C ABI in production) and the exchange
@@ -187,6 +197,12 @@ class HipEngine:
                                                 h._stream()))
 
 
+    def interface_pair(self, my_lo, my_hi, prev_hi, next_lo, nlines, xlo, xhi):
+        h = self.hip
+        self.check(self.lib.adi_interface_pair(h._p(my_lo), h._p(my_hi), h._p(prev_hi), h._p(next_lo), nlines,
+                                               h._p(xlo), h._p(xhi), h._stream()))
+
+
 def _interior(t_ext):
     """planes 1..n-2 of an extended array: same strides, pointer advanced by one plane"""
     return t_ext[1:-1]
@@ -215,7 +231,13 @@ class SlabStepper:
         self._ext_bufs = [self.Lext.empty(), self.Lext.empty()]
         self._cur = 0
         self._tmp = [self.Lext.empty(), self.Lext.empty()]
-        self._chunk_list = None
+        self._mask_version = 0
+        self._a0_key, self._a0, self.axis0_mode = None, None, None
+        self._no_overlap, self._force_exact = False, False
+        self._allow_window = True                  # False keeps 'window' plans off (whole-slab condensation only)
+        self._comm_stream, self._use_streams = None, False
+        self._halo_ready, self._halo_event = None, None
+        self._gam = 0.0
         self.set_mask(mask_local)
 
     @classmethod
@@ -229,6 +251,7 @@ class SlabStepper:
         """grid.mask = ...; packs = precompute_coeff_packs_unified(...) for this slab.  Exchanges the mask
         halo planes, rebuilds the neighbour flags and the coefficient packs on the extended slab."""
         E, L = self.engine, self.Lext
+        self._mask_version += 1
         m_ext = np.zeros((self.nxl + 2, self.ny, self.nz), dtype=np.bool_)
         m_ext[1:-1] = mask_local
         d_mask = L.to_layout(m_ext, torch.uint8)
@@ -258,15 +281,22 @@ class SlabStepper:
                                        ext(bc['dir_value'], 0.0), neumann, robin_h)
         self.variant = self.packs_ext[0].variant
         from . import _lib
-        bpc = [getattr(p, 'bytes_per_cell', float(_lib.SWEEP_BYTES_PER_CELL[self.variant])) for p in self.packs_ext]
-        self.stage_bytes_per_cell = [float(_lib.EXPLICIT_BYTES_PER_CELL),
-                                     (2 * (bpc[0] - 8) + 8) if self.world > 1 else bpc[0],   # pass A re-reads the inputs
-                                     bpc[1], bpc[2]]
+        self._bpc = [getattr(p, 'bytes_per_cell', float(_lib.SWEEP_BYTES_PER_CELL[self.variant])) for p in self.packs_ext]
+        self._explicit_bpc = float(_lib.EXPLICIT_BYTES_PER_CELL)
 
         def interior_pack(p):
             return tuple(None if t is None else _interior(t) for t in (p.d_coeff, p.d_dir_mask, p.d_dir_val, p.d_qflux))
         self.packs_int = [interior_pack(p) for p in self.packs_ext]
         self.flags_int = _interior(self.flags_ext)
+
+    @property
+    def stage_bytes_per_cell(self):
+        """algorithmic HBM bytes per local cell of the four stages (pass A re-reads the inputs of the rows it covers)"""
+        bpc = self._bpc
+        frac = 0.0
+        if self.world > 1:
+            frac = 1.0 if (self._a0 is None or self._a0['mode'] != 'window') else min(1.0, 2.0 * self._a0['K'] / self.nxl)
+        return [self._explicit_bpc, bpc[0] + frac * (bpc[0] - 8), bpc[1], bpc[2]]
 
     @staticmethod
     def local_numpy(T):
@@ -286,132 +316,302 @@ class SlabStepper:
                 self._cur = i
                 return buf
         buf = self._ext_bufs[self._cur]
+        self._halo_ready = None                    # a foreign field: whatever halo was prefetched is not its halo
         src = t if isinstance(t, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(t), dtype=np.float64))
         _interior(buf).copy_(src)
         return buf
 
-    def _chunks(self):
-        """(j0, j1) ranges: the lines of the sharded sweep are cut along j so that each chunk is a sub-box"""
-        if getattr(self, '_chunk_list', None) is None:
-            nch = 4 if (self.ny >= 32) else 1
-            edges = [round(i * self.ny / nch) for i in range(nch + 1)]
-            self._chunk_list = [(edges[i], edges[i + 1]) for i in range(nch) if edges[i + 1] > edges[i]]
-            E = self.engine
-            self._chunk_bufs = []
-            for j0, j1 in self._chunk_list:
-                nl = (j1 - j0) * self.nz
-                self._chunk_bufs.append(dict(L=E.layout(self.nxl, j1 - j0, self.nz, self.Lint.sx), nl=nl, cond=E.vec(6 * nl),
-                                             cond_all=E.vec(6 * nl * self.world), xlo=E.vec(nl), xhi=E.vec(nl)))
-            self._use_streams = (E.device.type == 'cuda') and isinstance(self.comm, TorchDistComm) \
-                and not getattr(self, '_no_overlap', False)
-            if self._use_streams:
-                self._comm_stream = torch.cuda.Stream(device=E.device)
-        return self._chunk_list
+    # -- how the axis-0 interface system is solved ------------------------------------------------------
+    DECAY_TOL = 1e-17      # |aL|, |cF| at or below this are dropped (they multiply values of the size of the data)
 
-    def _axis0_distributed(self, Ai, Bi, gam):
+    def _chunk_ranges(self, nch):
+        nch = nch if self.ny >= 8 * nch else 1
+        edges = [round(i * self.ny / nch) for i in range(nch + 1)]
+        return [(edges[i], edges[i + 1]) for i in range(nch) if edges[i + 1] > edges[i]]
+
+    def _streams(self):
+        E = self.engine
+        self._use_streams = (E.device.type == 'cuda') and isinstance(self.comm, TorchDistComm) \
+            and not self._no_overlap
+        if self._use_streams and self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=E.device)
+        return self._use_streams
+
+    def _window_guess(self, gam):
+        """rows after which the coupling through a run of interior rows (-tg, 1+2tg, -tg) has decayed below
+        DECAY_TOL: rho = 2tg / (1 + 2tg + sqrt(1 + 4tg)) per row; every other row is more dominant"""
+        tg = self.params.theta * gam
+        if tg <= 0.0:
+            return 8
+        rho = 2.0 * tg / (1.0 + 2.0 * tg + np.sqrt(1.0 + 4.0 * tg))
+        need = int(np.ceil(np.log(self.DECAY_TOL) / np.log(rho))) + 2
+        K = 8
+        while K < need:            # powers of two: the in-register condensation kernels tile those
+            K *= 2
+        return K
+
+    def _plan_axis0(self, Ti, gam):
+        """-> plan dict for the current (dt, theta, mask): mode 'exact' | 'window' (first/last K planes) |
+        'slab' (the whole slab is its own window).  Collective: every rank calls it at the same step."""
+        prm = self.params
+        key = (float(prm.dt), float(prm.theta), self._mask_version, self._force_exact, self._no_overlap)
+        if self._a0_key == key:
+            return self._a0
+        E, v = self.engine, self.variant
+        self._streams()
+        nl, fl, pk = self.nlines, self.flags_int, self.packs_int[0]
+        first, last = self.rank == 0, self.rank == self.world - 1
+        plan = None
+        if not self._force_exact:
+            K = self._window_guess(gam)
+            # windows pay off when they are a small part of the slab (pass A on 2K planes instead of all of them)
+            tries = ([('window', K)] if 4 * K <= self.nxl else []) + [('slab', self.nxl)]
+            for mode, k in tries:
+                if mode == 'window' and not self._allow_window:
+                    continue
+                Lw = E.layout(k, self.ny, self.nz, self.Lint.sx)
+                worst = 0.0
+                c = E.vec(6 * nl)
+                if not first:      # first-rows window: (gF, aF) are used, cF must have decayed
+                    E.condense(0, v, Lw, Ti[:k], fl[:k], tuple(None if t is None else t[:k] for t in pk), prm.theta,
+                               gam, prm.dt, self.Tinf, c)
+                    worst = max(worst, float(c.view(6, nl)[2].abs().max()))
+                if not last:       # last-rows window: (gL, cL) are used, aL must have decayed
+                    o = self.nxl - k
+                    E.condense(0, v, Lw, Ti[o:], fl[o:], tuple(None if t is None else t[o:] for t in pk), prm.theta,
+                               gam, prm.dt, self.Tinf, c)
+                    worst = max(worst, float(c.view(6, nl)[4].abs().max()))
+                if worst <= self.DECAY_TOL:          # NaN compares false -> next try / exact
+                    plan = dict(mode=mode, K=k, Lw=Lw, worst=worst)
+                    break
+        flag = E.vec(1); flag.fill_(1.0 if plan is not None else 0.0)
+        allf = E.vec(self.world)
+        self.comm.all_gather(allf, flag)
+        if float(allf.min()) < 1.0:
+            plan = None
+        if plan is None:
+            plan = dict(mode='exact', K=self.nxl)
+            ranges = self._chunk_ranges(4)
+        else:
+            # a window's exchange hides behind the explicit stage of the middle planes; a whole-slab condensation
+            # is pipelined over chunks of lines instead
+            ranges = self._chunk_ranges(1 if plan['mode'] == 'window' else 2)
+        bufs = []
+        for j0, j1 in ranges:
+            n = (j1 - j0) * self.nz
+            Lc = E.layout(plan['K'], j1 - j0, self.nz, self.Lint.sx)
+            Lb = E.layout(self.nxl, j1 - j0, self.nz, self.Lint.sx)
+            b = dict(j0=j0, j1=j1, nl=n, Lc=Lc, Lb=Lb, xlo=E.vec(n), xhi=E.vec(n))
+            if plan['mode'] == 'exact':
+                b.update(cond=E.vec(6 * n), cond_all=E.vec(6 * n * self.world))
+            else:
+                b['cond_hi'] = E.vec(6 * n)
+                b['cond_lo'] = E.vec(6 * n) if plan['mode'] == 'window' else b['cond_hi']
+                b['prev_hi'] = E.vec(3 * n)        # (gL, aL, cL) of the slab below
+                b['next_lo'] = E.vec(2 * n)        # (gF, aF) of the slab above
+            bufs.append(b)
+        plan['chunks'] = bufs
+        self._a0_key, self._a0 = key, plan
+        self.axis0_mode = plan['mode']
+        return plan
+
+    def _condense_windows(self, plan, Ai, b):
+        """pass A on one chunk of lines: the condensations this rank's neighbours need"""
+        E, prm, v, K = self.engine, self.params, self.variant, plan['K']
+        gam = self._gam
+        j0, j1 = b['j0'], b['j1']
+        fl, pk = self.flags_int, self.packs_int[0]
+        cut = lambda t, p0, p1: None if t is None else t[p0:p1, j0:j1, :]
+        if plan['mode'] == 'exact':
+            E.condense(0, v, b['Lb'], cut(Ai, 0, self.nxl), cut(fl, 0, self.nxl), tuple(cut(t, 0, self.nxl) for t in pk),
+                       prm.theta, gam, prm.dt, self.Tinf, b['cond'])
+            return
+        n = self.nxl
+        if plan['mode'] == 'slab':
+            if self.world > 1:
+                E.condense(0, v, b['Lb'], cut(Ai, 0, n), cut(fl, 0, n), tuple(cut(t, 0, n) for t in pk), prm.theta, gam,
+                           prm.dt, self.Tinf, b['cond_hi'])
+            return
+        if self.rank > 0:
+            E.condense(0, v, b['Lc'], cut(Ai, 0, K), cut(fl, 0, K), tuple(cut(t, 0, K) for t in pk), prm.theta, gam,
+                       prm.dt, self.Tinf, b['cond_lo'])
+        if self.rank < self.world - 1:
+            E.condense(0, v, b['Lc'], cut(Ai, n - K, n), cut(fl, n - K, n), tuple(cut(t, n - K, n) for t in pk), prm.theta,
+                       gam, prm.dt, self.Tinf, b['cond_hi'])
+
+    def _exchange_interface(self, plan, b):
+        if plan['mode'] == 'exact':
+            self.comm.all_gather(b['cond_all'], b['cond'])
+        else:
+            n = b['nl']
+            self.comm.exchange_planes(b['cond_lo'].view(6, n)[0:2], b['cond_hi'].view(6, n)[3:6],
+                                      b['prev_hi'].view(3, n), b['next_lo'].view(2, n))
+
+    def _solve_and_sweep(self, plan, Ai, Bi, b):
+        """interface values of one chunk of lines, then pass B: the local sweep with them injected"""
         E, prm, v = self.engine, self.params, self.variant
-        chunks = self._chunks()
-        fl = self.flags_int
-        pk = self.packs_int[0]
+        j0, j1, n = b['j0'], b['j1'], self.nxl
+        fl, pk = self.flags_int, self.packs_int[0]
+        if plan['mode'] == 'exact':
+            E.interface(b['cond_all'], self.world, self.rank, b['nl'], b['xlo'], b['xhi'])
+        else:
+            E.interface_pair(b['cond_lo'], b['cond_hi'], b['prev_hi'] if self.rank > 0 else None,
+                             b['next_lo'] if self.rank < self.world - 1 else None, b['nl'], b['xlo'], b['xhi'])
+        cut = lambda t: None if t is None else t[:, j0:j1, :]
+        E.sweep(0, v, b['Lb'], cut(Ai), cut(fl), tuple(cut(t) for t in pk), prm.theta, self._gam, prm.dt, self.Tinf,
+                cut(Bi), b['xlo'], b['xhi'])
 
-        def sub(t, j0, j1):
-            return None if t is None else t[:, j0:j1, :]
+    def _axis0_pipeline(self, plan, Ai, Bi, condensed=False):
+        """pass A, exchange, interface solve and pass B over the chunks of lines; with RCCL the exchange of chunk c
+        runs on a second stream while chunk c+1 is condensed and chunk c-1 is solved."""
+        bufs = plan['chunks']
         use_streams = self._use_streams
         main = torch.cuda.current_stream() if use_streams else None
-        ev_cond, ev_ag = [], []
-        for (j0, j1), cb in zip(chunks, self._chunk_bufs):           # pass A for every chunk
-            E.condense(0, v, cb['L'], sub(Ai, j0, j1), sub(fl, j0, j1), tuple(sub(t, j0, j1) for t in pk),
-                       prm.theta, gam, prm.dt, self.Tinf, cb['cond'])
+        ev_a, ev_x = [], []
+        for b in bufs:
+            if not condensed:
+                self._condense_windows(plan, Ai, b)
             if use_streams:
-                e = torch.cuda.Event(); e.record(main); ev_cond.append(e)
+                e = torch.cuda.Event(); e.record(main); ev_a.append(e)
         if use_streams:
-            with torch.cuda.stream(self._comm_stream):                 # all-gathers on the second stream
-                for cb, e in zip(self._chunk_bufs, ev_cond):
+            with torch.cuda.stream(self._comm_stream):
+                for b, e in zip(bufs, ev_a):
                     self._comm_stream.wait_event(e)
-                    self.comm.all_gather(cb['cond_all'], cb['cond'])
-                    e2 = torch.cuda.Event(); e2.record(self._comm_stream); ev_ag.append(e2)
-        for i, ((j0, j1), cb) in enumerate(zip(chunks, self._chunk_bufs)):   # interface + pass B per chunk
+                    self._exchange_interface(plan, b)
+                    e2 = torch.cuda.Event(); e2.record(self._comm_stream); ev_x.append(e2)
+        return ev_x
+
+    def _axis0_finish(self, plan, Ai, Bi, ev_x):
+        use_streams = self._use_streams
+        main = torch.cuda.current_stream() if use_streams else None
+        for i, b in enumerate(plan['chunks']):
             if use_streams:
-                main.wait_event(ev_ag[i])
+                main.wait_event(ev_x[i])
             else:
-                self.comm.all_gather(cb['cond_all'], cb['cond'])
-            E.interface(cb['cond_all'], self.world, self.rank, cb['nl'], cb['xlo'], cb['xhi'])
-            E.sweep(0, v, cb['L'], sub(Ai, j0, j1), sub(fl, j0, j1), tuple(sub(t, j0, j1) for t in pk), prm.theta, gam,
-                    prm.dt, self.Tinf, sub(Bi, j0, j1), cb['xlo'], cb['xhi'])
+                self._exchange_interface(plan, b)
+            self._solve_and_sweep(plan, Ai, Bi, b)
 
     def self_check(self, T):
-        """One step with the second-stream pipeline and one with every exchange on the main stream, from the same
-        input; they must agree to rounding.  If they do not (a stream-ordering problem on this software stack), the
-        pipeline is switched off for the rest of the run.  Returns (max relative difference, overlap enabled)."""
+        """One step as configured (neighbour-only interface solve where the decay allows it, exchanges on the
+        second stream) and one with the exact all-gather solve and every exchange on the main stream, from the same
+        input; they must agree to rounding.  If they do not (a stream-ordering problem on this software stack),
+        the conservative configuration is kept for the rest of the run.
+        Returns (max relative difference, fast configuration enabled)."""
         t = T.t if hasattr(T, 't') and not isinstance(T, torch.Tensor) else T
         src = t.clone()
         a = self.step(src)
         a = (a.t if hasattr(a, 't') and not isinstance(a, torch.Tensor) else a).clone()
-        self._no_overlap = True
-        self._chunk_list = None
+        keep = (self._no_overlap, self._force_exact)
+        self._no_overlap, self._force_exact = True, True
         b = self.step(src)
         b = b.t if hasattr(b, 't') and not isinstance(b, torch.Tensor) else b
         den = float(b.abs().max())
         err = float((a - b).abs().max()) / (den if den > 0 else 1.0)
-        if err <= 1e-12:
-            self._no_overlap = False
-            self._chunk_list = None
+        ok = torch.tensor([1.0 if err <= 1e-12 else 0.0], dtype=torch.float64, device=self.engine.device)
+        allok = self.engine.vec(self.world)
+        self.comm.all_gather(allok, ok)                 # the ranks must not end up in different configurations
+        if float(allok.min()) >= 1.0:
+            self._no_overlap, self._force_exact = keep
         return err, not self._no_overlap
 
-    def step(self, T, events=None):
+    def step(self, T, events=None, prefetch_halo=False):
+        """One ADI step of the local slab.  prefetch_halo=True promises that the returned field is passed to the
+        next step() unmodified (an nsub loop).  Used by the 'window' form, whose step starts with the planes next
+        to the halos: the boundary planes of the result are then computed first and sent to the neighbours while
+        the rest of the last sweep runs.  (The other forms start with the planes that need no halo, which hides
+        the exchange just as well.)"""
         E, prm, mat = self.engine, self.params, self.mat
         kappa = mat.k / (mat.rho * mat.cp)                       # adi3d_numba_coeff.py:292
-        gam = kappa * prm.dt / (self.dx * self.dx)
+        gam = self._gam = kappa * prm.dt / (self.dx * self.dx)
         kind = 'torch' if isinstance(T, torch.Tensor) else ('numpy' if isinstance(T, np.ndarray) else 'field')
         Text = self._load_state(T)
         nxt = self._ext_bufs[self._cur ^ 1]
         A, B = self._tmp
+        Ai, Bi, Oi = _interior(A), _interior(B), _interior(nxt)
+        v, Li, fl = self.variant, self.Lint, self.flags_int
+        nl = self.nxl
 
         def mark(i):
             if events is not None:
                 events[i].record()
         mark(0)
-        # 1. state halos (zeros outside the global grid are never read: the flags carry no coupling there)
-        # 2. explicit stage: the planes that do not touch a halo run while the halo planes are in flight
-        lo = Text[0]; hi = Text[-1]
-        self._chunks()
-        nl = self.nxl
-        overlap = self._use_streams and self.world > 1
-        ev1 = None
-        if overlap:
-            main = torch.cuda.current_stream()
-            ev0 = torch.cuda.Event(); ev0.record(main)
-            with torch.cuda.stream(self._comm_stream):
-                self._comm_stream.wait_event(ev0)                       # Text is complete
-                self.comm.exchange_planes(Text[1], Text[-2], lo, hi)
-                ev1 = torch.cuda.Event(); ev1.record(self._comm_stream)
-        else:
-            self.comm.exchange_planes(Text[1], Text[-2], lo, hi)
+        plan = self._plan_axis0(_interior(Text), gam) if self.world > 1 else None
+        streams = self._streams() and self.world > 1
+        main = torch.cuda.current_stream() if streams else None
         ex = lambda b, e: E.explicit(self.Lext, Text, self.flags_ext, self.dx, prm.dt, kappa, prm.theta, A, b, e)
-        if self.world > 1 and nl >= 4:
-            ex(2, nl)                        # planes that touch no halo
-            if ev1 is not None:
-                main.wait_event(ev1)
-            ex(1, 2)                         # first and last local plane need the neighbours' planes
-            ex(nl, nl + 1)
-        else:
-            if ev1 is not None:
-                main.wait_event(ev1)
+
+        # 1. state halos (zeros outside the global grid are never read: the flags carry no coupling there)
+        halo_ev = None
+        if self._halo_ready == self._cur and self._halo_ready is not None:
+            halo_ev = self._halo_event                       # sent at the end of the previous step
+        elif self.world > 1:
+            lo, hi = Text[0], Text[-1]
+            if streams:
+                ev0 = torch.cuda.Event(); ev0.record(main)
+                with torch.cuda.stream(self._comm_stream):
+                    self._comm_stream.wait_event(ev0)                   # Text is complete
+                    self.comm.exchange_planes(Text[1], Text[-2], lo, hi)
+                    halo_ev = torch.cuda.Event(); halo_ev.record(self._comm_stream)
+            else:
+                self.comm.exchange_planes(Text[1], Text[-2], lo, hi)
+        self._halo_ready = None
+
+        # 2. explicit stage, 3. axis-0 sweep
+        if self.world == 1:
             ex(1, nl + 1)
-        mark(1)
-        Ai, Bi, Oi = _interior(A), _interior(B), _interior(nxt)
-        v, Li, fl = self.variant, self.Lint, self.flags_int
-        # 3. distributed axis-0 sweep, pipelined over chunks of lines (ranges of j): the all-gather of chunk c
-        #    runs on a second stream while chunk c+1 is condensed and chunk c-1 is solved
-        if self.world > 1:
-            self._axis0_distributed(Ai, Bi, gam)
-        else:
+            mark(1)
             E.sweep(0, v, Li, Ai, fl, self.packs_int[0], prm.theta, gam, prm.dt, self.Tinf, Bi)
+        elif plan['mode'] == 'window':
+            # the boundary windows first: their condensation travels while the middle planes are computed
+            K = plan['K']
+            if halo_ev is not None and streams:
+                main.wait_event(halo_ev)
+            if 2 * K < nl:
+                ex(1, K + 1); ex(nl - K + 1, nl + 1)
+            else:
+                ex(1, nl + 1)
+            ev_x = self._axis0_pipeline(plan, Ai, Bi)
+            if 2 * K < nl:
+                ex(K + 1, nl - K + 1)
+            mark(1)
+            self._axis0_finish(plan, Ai, Bi, ev_x)
+        else:
+            # the planes that touch no halo run while the halo planes are in flight
+            if nl >= 4:
+                ex(2, nl)
+                if halo_ev is not None and streams:
+                    main.wait_event(halo_ev)
+                ex(1, 2); ex(nl, nl + 1)
+            else:
+                if halo_ev is not None and streams:
+                    main.wait_event(halo_ev)
+                ex(1, nl + 1)
+            mark(1)
+            ev_x = self._axis0_pipeline(plan, Ai, Bi)
+            self._axis0_finish(plan, Ai, Bi, ev_x)
         mark(2)
         # 4. local sweeps
         E.sweep(1, v, Li, Bi, fl, self.packs_int[1], prm.theta, gam, prm.dt, self.Tinf, Ai)
         mark(3)
-        E.sweep(2, v, Li, Ai, fl, self.packs_int[2], prm.theta, gam, prm.dt, self.Tinf, Oi)
+        pk2 = self.packs_int[2]
+        sw2 = lambda p0, p1: E.sweep(2, v, E.layout(p1 - p0, self.ny, self.nz, Li.sx), Ai[p0:p1], fl[p0:p1],
+                                     tuple(None if t is None else t[p0:p1] for t in pk2), prm.theta, gam, prm.dt,
+                                     self.Tinf, Oi[p0:p1])
+        if prefetch_halo and self.world > 1 and nl >= 4 and plan['mode'] == 'window':
+            sw2(0, 1); sw2(nl - 1, nl)                        # the two planes the neighbours need
+            if streams:
+                ev0 = torch.cuda.Event(); ev0.record(main)
+                with torch.cuda.stream(self._comm_stream):
+                    self._comm_stream.wait_event(ev0)
+                    self.comm.exchange_planes(nxt[1], nxt[-2], nxt[0], nxt[-1])
+                    self._halo_event = torch.cuda.Event(); self._halo_event.record(self._comm_stream)
+            else:
+                self.comm.exchange_planes(nxt[1], nxt[-2], nxt[0], nxt[-1])
+                self._halo_event = None
+            self._halo_ready = self._cur ^ 1
+            sw2(1, nl - 1)
+        else:
+            sw2(0, nl)
         mark(4)
         self._cur ^= 1
         if kind == 'numpy':

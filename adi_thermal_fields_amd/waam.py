@@ -191,8 +191,8 @@ def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, 
         nonlocal T, nsteps
         nsub = max(1, int(math.ceil(seg / dt_cap)))
         params.dt = max(seg / nsub, 1e-15)
-        for _ in range(nsub):
-            T = st.step(T)
+        for s in range(nsub):
+            T = st.step(T, prefetch_halo=(s + 1 < nsub))
         nsteps += nsub
 
     events = sorted(set(list(times_out) + list(times_birth)))

@@ -118,14 +118,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    kw = dict(prefetch_halo=True) if world > 1 else {}     # the loop feeds every step's output to the next unmodified
     for _ in range(a.warmup):
-        T = stepper.step(T)
+        T = stepper.step(T, **kw)
     nst = len(stage_names)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(a.steps)]
     sync()
     t0 = time.perf_counter()
     for s in range(a.steps):
-        T = stepper.step(T, events=ev[s])     # HIP events on the launch stream between the stage kernels
+        T = stepper.step(T, events=ev[s], **kw)     # HIP events on the launch stream between the stage kernels
     sync()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
@@ -193,7 +194,8 @@ def main():
                     sweep_variant={0: 'general', 1: 'no_dir', 2: 'no_q', 3: 'lean'}[variant]),
         cell_updates_per_s=round(world * N * a.steps / elapsed, 1),
         step_achieved_gbs=round(sum(bytes_per_cell.values()) * N / (ms_per_step * 1e-3) / 1e9, 1),
-        **({'comm_overlap': dict(enabled=overlap_on, selfcheck_rel_diff=overlap_err)} if world > 1 else {}),
+        **({'comm_overlap': dict(enabled=overlap_on, selfcheck_rel_diff=overlap_err,
+                                 axis0_interface=stepper.axis0_mode)} if world > 1 else {}),
         roofline=dict(bound='hbm', kernel=dom, achieved=kernels[dom]['achieved_gbs'], peak=HBM_PEAK_GBS,
                       unit='GB/s', frac=kernels[dom]['frac'], traffic=traffic),
         kernels=kernels,

@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 5
+#define ADI_ABI_VERSION 6
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -142,6 +142,13 @@ int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t 
  * interface system of every line and writes this rank's boundary values for pass B (adi_sweep). */
 int adi_interface_solve(const double *d_cond_all, int nranks, int rank, long nlines,
                         double *d_xlo, double *d_xhi, void *stream);
+/* Neighbour-only interface solve, for slabs thick enough that the coupling across a boundary window has decayed
+ * below rounding (the caller checks |aL| of its last-rows window and |cF| of its first-rows window).
+ * d_my_lo / d_my_hi: [6][nlines] pass-A output of this slab's first / last window of planes;
+ * d_prev_hi: rows 3..5 (gL, aL, cL) of the last window of the slab below, d_next_lo: rows 0..1 (gF, aF) of the
+ * first window of the slab above; NULL where there is no neighbour (boundary value 0, never used). */
+int adi_interface_pair(const double *d_my_lo, const double *d_my_hi, const double *d_prev_hi, const double *d_next_lo,
+                       long nlines, double *d_xlo, double *d_xhi, void *stream);
 
 /*
  * adi_step_numba_coeff / adi_step_gpu_coeff: adi3d_numba_coeff.py:290-302, adi3d_gpu_coeff.py:213-230.

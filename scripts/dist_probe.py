@@ -17,9 +17,9 @@ class FakeComm:
 
     def exchange_planes(self, send_lo, send_hi, recv_lo, recv_hi):
         if self.rank > 0:
-            recv_lo.copy_(send_lo)
+            recv_lo.copy_(send_hi)          # what a copy of this rank sitting below would send up
         if self.rank < self.world - 1:
-            recv_hi.copy_(send_hi)
+            recv_hi.copy_(send_lo)
 
     def all_gather(self, out, inp):
         out.view(self.world, -1).copy_(inp.view(1, -1).expand(self.world, -1))
@@ -31,19 +31,24 @@ def main():
     mat = adi.Material(7800.0, 490.0, 54.0)
     alpha = mat.k / (mat.rho * mat.cp)
     dx = 5e-4
-    prm = adi.Params(200.0 * dx * dx / alpha, 0.5)
+    import os
+    prm = adi.Params(float(os.environ.get('PROBE_CFL', '200')) * dx * dx / alpha, 0.5)
     dev = torch.device('cuda')
     T = adi.DeviceField(torch.rand((n, n, n), dtype=torch.float64, device=dev) * 980 + 20)
     st = dist_slab.SlabStepper(np.ones((n, n, n), bool), dx, mat, prm, 20.0, robin_h=500.0,
                                comm=FakeComm(world, world // 2))
+    import os
+    st._force_exact = bool(int(os.environ.get('PROBE_EXACT', '0')))
+    pre = bool(int(os.environ.get('PROBE_PREFETCH', '1')))
     for _ in range(3):
-        T = st.step(T)
+        T = st.step(T, prefetch_halo=pre)
     torch.cuda.synchronize()
+    print('axis-0 interface form:', st.axis0_mode, 'K =', st._a0['K'], 'chunks =', len(st._a0['chunks']))
     K = 10
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(K)]
     t0 = time.perf_counter()
     for s in range(K):
-        T = st.step(T, events=ev[s])
+        T = st.step(T, events=ev[s], prefetch_halo=pre)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K * 1e3
     ms = np.array([[ev[s][i].elapsed_time(ev[s][i + 1]) for i in range(4)] for s in range(K)]).mean(axis=0)
@@ -84,5 +89,5 @@ def parts():
     print('pass A %.3f ms, interface %.3f ms, pass B %.3f ms' % (a, b, c))
 
 
-if len(sys.argv) > 3:
+if __name__ == '__main__' and len(sys.argv) > 3:
     parts()

@@ -145,3 +145,19 @@ class CpuEngine:
             z = np.linalg.solve(A, rhs)
             lo[l] = z[2 * rank - 1] if rank > 0 else 0.0
             hi[l] = z[2 * rank + 2] if rank < world - 1 else 0.0
+
+    def interface_pair(self, my_lo, my_hi, prev_hi, next_lo, nlines, xlo, xhi):
+        """neighbour-only interface values: per line the 2x2 system between the last window of one slab and the
+        first window of the next, written out with a dense solve (independent of the product's closed form)"""
+        lo = xlo.numpy(); hi = xhi.numpy()
+        lo[:] = 0.0; hi[:] = 0.0
+        if prev_hi is not None:
+            P = prev_hi.view(3, nlines).numpy(); C = my_lo.view(6, nlines).numpy()
+            for l in range(nlines):       # unknowns (last of slab below, my first)
+                M = np.array([[1.0, P[2, l]], [C[1, l], 1.0]])
+                lo[l] = np.linalg.solve(M, np.array([P[0, l], C[0, l]]))[0]
+        if next_lo is not None:
+            N = next_lo.view(2, nlines).numpy(); C = my_hi.view(6, nlines).numpy()
+            for l in range(nlines):       # unknowns (my last, first of slab above)
+                M = np.array([[1.0, C[5, l]], [N[1, l], 1.0]])
+                hi[l] = np.linalg.solve(M, np.array([C[3, l], N[0, l]]))[1]

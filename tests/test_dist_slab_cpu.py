@@ -19,7 +19,25 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case_name, sizes, nsteps, q):
+def _decay_case(nx):
+    """small time step: the interface coupling decays within ~16 rows, so thick slabs take the neighbour-only
+    interface solve ('window' when the slab holds two windows, 'slab' otherwise)"""
+    rng = np.random.default_rng(11)
+    shape = (nx, 4, 5)
+    mask = rng.random(shape) > 0.1
+    dx = 1e-3
+    mat = dict(rho=7800.0, cp=490.0, k=54.0)
+    alpha = mat['k'] / (mat['rho'] * mat['cp'])
+    return dict(shape=shape, dx=dx, mat=mat, mask=mask, T0=rng.uniform(20.0, 1500.0, shape), dir_mask=None,
+                dir_value=None, neumann={'x+': 2e5}, robin_h=400.0, Tinf=20.0, theta=0.5, dt=0.1 * dx * dx / alpha,
+                nsteps=3, births=None)
+
+
+def _case(name):
+    return _decay_case(int(name.split(':')[1])) if name.startswith('decay:') else cases.cart_case(name)
+
+
+def _worker(rank, world, port, case_name, sizes, nsteps, q, opts=None):
     sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
@@ -28,7 +46,8 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q):
         from adi_thermal_fields_amd import dist_slab
         from cpu_engine import CpuEngine
         from oracle import adi_oracle as orc
-        c = cases.cart_case(case_name)
+        c = _case(case_name)
+        opts = opts or {}
         i0 = sum(sizes[:rank]); i1 = i0 + sizes[rank]
 
         def loc(a):
@@ -39,10 +58,12 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q):
                                    orc.Params(c['dt'], c['theta']), c['Tinf'], dir_mask=loc(c['dir_mask']),
                                    dir_value=loc(c['dir_value']), neumann=neumann, robin_h=robin_h,
                                    comm=dist_slab.TorchDistComm(), engine=CpuEngine())
+        st._force_exact = bool(opts.get('force_exact', False))
+        st._allow_window = bool(opts.get('allow_window', True))
         T = torch.from_numpy(np.ascontiguousarray(c['T0'][i0:i1]))
-        for _ in range(nsteps):
-            T = st.step(T)
-        q.put((rank, T.numpy().copy()))
+        for s in range(nsteps):
+            T = st.step(T, prefetch_halo=bool(opts.get('prefetch', False)) and s + 1 < nsteps)
+        q.put((rank, T.numpy().copy(), st.axis0_mode))
     finally:
         dist.destroy_process_group()
 
@@ -65,7 +86,7 @@ def test_slab_decomposition_matches_single_domain(world, case_name):
     procs = [ctx.Process(target=_worker, args=(r, world, port, case_name, sizes, nsteps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    parts = dict(q.get(timeout=120) for _ in range(world))
+    parts = {r: t for r, t, _ in (q.get(timeout=120) for _ in range(world))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -73,6 +94,51 @@ def test_slab_decomposition_matches_single_domain(world, case_name):
     c2 = dict(c); c2['nsteps'] = nsteps
     want = run_cart_case(orc, c2)['T_final']
     assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
+
+
+def _run_world(world, case_name, sizes, nsteps, opts):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case_name, sizes, nsteps, q, opts)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    parts = {r: t for r, t, _ in res}
+    modes = {m for _, _, m in res}
+    return np.concatenate([parts[r] for r in range(world)], axis=0), modes
+
+
+@pytest.mark.parametrize('world,nx,opts,mode', [
+    (2, 128, dict(prefetch=True), 'window'),         # 64 planes per rank, 16-row windows at both ends
+    (3, 72, dict(prefetch=True), 'slab'),            # 24 planes: the whole slab is the window
+    (2, 128, dict(allow_window=False), 'slab'),
+    (2, 128, dict(force_exact=True, prefetch=True), 'exact'),
+])
+def test_neighbour_only_interface_matches_single_domain(world, nx, opts, mode):
+    """thick slabs / small dt: the reduced system splits into 2x2 neighbour systems (dist_slab docstring); the result
+    must still be the single-domain step to rounding, and all three forms must agree"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import adi_oracle as orc
+    from helpers import run_cart_case, rel_linf
+    name = 'decay:%d' % nx
+    c = _case(name)
+    got, modes = _run_world(world, name, [nx // world] * world, c['nsteps'], opts)
+    assert modes == {mode}, modes
+    want = run_cart_case(orc, c)['T_final']
+    assert rel_linf(got, want) <= 1e-13, rel_linf(got, want)
+
+
+def test_thin_slabs_fall_back_to_exact():
+    """coupling that has not decayed across the middle slab (cfl 200, 4 planes) must select the all-gather solve;
+    with two ranks the neighbour-only form is exact whatever the decay (no slab has neighbours on both sides)"""
+    got, modes = _run_world(3, 'holes_mixed', [5, 4, 4], 1, {})
+    assert modes == {'exact'}, modes
+    got, modes = _run_world(2, 'holes_mixed', [7, 6], 1, {})
+    assert modes == {'slab'}, modes
 
 
 def test_split_planes_even():

@@ -11,7 +11,7 @@ from helpers import rel_linf, run_cart_case
 pytestmark = pytest.mark.gpu
 
 
-def _run_slabs(c, world, sizes, nsteps):
+def _run_slabs(c, world, sizes, nsteps, opts=None, modes=None):
     import torch
     from adi_thermal_fields_amd import dist_slab
     import adi_thermal_fields_amd.adi3d_hip_coeff as hip
@@ -32,10 +32,15 @@ def _run_slabs(c, world, sizes, nsteps):
                                        hip.Params(c['dt'], c['theta']), c['Tinf'], dir_mask=loc(c['dir_mask']),
                                        dir_value=loc(c['dir_value']), neumann=neumann, robin_h=robin_h,
                                        comm=comms[rank])
+            o = opts or {}
+            st._force_exact = bool(o.get('force_exact', False))
+            st._allow_window = bool(o.get('allow_window', True))
             T = hip.to_device(np.ascontiguousarray(c['T0'][i0:i1]))
-            for _ in range(nsteps):
-                T = st.step(T)
+            for s in range(nsteps):
+                T = st.step(T, prefetch_halo=bool(o.get('prefetch', False)) and s + 1 < nsteps)
             out[rank] = T.get()
+            if modes is not None:
+                modes.add(st.axis0_mode)
         except Exception as e:   # surface the failure and release the other ranks
             errs.append(e)
             comms[rank].sh.barrier.abort()
@@ -81,3 +86,42 @@ def test_slabs_even_sizes_fast_condense_512_lines():
     got = _run_slabs(c, 4, [64, 64, 64, 64], 2)
     want = run_cart_case(hip, c)['T_final']
     assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
+
+
+@pytest.mark.parametrize('cfl,opts,mode', [(0.1, dict(prefetch=True), 'window'), (3.0, dict(prefetch=True), 'slab'),
+                                           (0.1, dict(allow_window=False), 'slab'), (300.0, dict(prefetch=True), 'exact'),
+                                           (0.1, dict(force_exact=True), 'exact')])
+def test_slabs_interface_forms_agree(cfl, opts, mode):
+    """4 slabs of 64 planes: neighbour-only interface solve on 16-plane windows (cfl 0.1), on whole slabs (cfl 3),
+    all-gather solve (cfl 300: no decay) -- each against the single-domain HIP step"""
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    rng = np.random.default_rng(7)
+    shape = (256, 10, 40)
+    mask = rng.random(shape) > 0.05
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,
+             T0=rng.uniform(20.0, 1200.0, shape), dir_mask=None, dir_value=None, neumann={'x-': 4e5},
+             robin_h=350.0, Tinf=20.0, theta=0.5, dt=cfl * dx * dx / alpha, nsteps=3, births=None)
+    modes = set()
+    got = _run_slabs(c, 4, [64, 64, 64, 64], 3, opts, modes)
+    assert modes == {mode}, modes
+    want = run_cart_case(hip, c)['T_final']
+    assert rel_linf(got, want) <= 1e-13, rel_linf(got, want)
+
+
+def test_slabs_window_solid_512_lines():
+    """all-solid grid (the FAST uniform-interior kernels) on 2 slabs of 256 planes, 32-plane windows"""
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    rng = np.random.default_rng(8)
+    shape = (512, 16, 64)
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=np.ones(shape, bool),
+             T0=rng.uniform(20.0, 1200.0, shape), dir_mask=None, dir_value=None, neumann=None,
+             robin_h=500.0, Tinf=20.0, theta=0.5, dt=1.0 * dx * dx / alpha, nsteps=2, births=None)
+    modes = set()
+    got = _run_slabs(c, 2, [256, 256], 2, dict(prefetch=True), modes)
+    assert modes == {'window'}, modes
+    want = run_cart_case(hip, c)['T_final']
+    assert rel_linf(got, want) <= 1e-13, rel_linf(got, want)
