@@ -1070,8 +1070,8 @@ __global__ __launch_bounds__(256) void k_explicit_v2(const double *__restrict__ 
 // planes with a three-plane register window, so every T value is loaded from memory once per chunk (plus the two
 // j-halo rows per plane, which the neighbouring tile of the same XCD has just touched); the j-neighbours of a row are
 // in the same thread's registers, the k-neighbours in the adjacent lanes.  Same expression order as v2 / the reference.
-constexpr int JT3 = 4;
 
+template <int JT3>
 __global__ __launch_bounds__(256) void k_explicit_v3(const double *__restrict__ T, const uint8_t *__restrict__ flags,
                                                      double *__restrict__ R0, Lay L, double invdx2, double f,
                                                      int jslab, int ktiles, int ichunk, long ntiles, int i_begin,
@@ -1162,6 +1162,127 @@ __global__ __launch_bounds__(256) void k_explicit_v3(const double *__restrict__ 
         }
 #pragma unroll
         for (int r = 0; r < JT3; ++r) { tm[r] = tc[r]; tc[r] = tp[r]; }
+    }
+}
+
+// k_explicit_v5 (default): v3 software-pipelined one plane ahead.  The loads issued while plane i is computed are those of
+// plane i+2 (state), and of plane i+1 (flags, j-halo rows, k-edge values), so that a wave always has a full plane of
+// loads in flight behind its arithmetic and stores instead of load -> wait -> compute -> store in sequence.
+// The two k-edge values of a row come from ONE load (lane 0 fetches k0-1, lane 63 fetches k0+2).
+// Measured at 512^3: v3 0.50 ms, v5 with 4-row tiles 0.47 ms (158 VGPRs, 3 waves/SIMD), with 2-row tiles 0.466 ms
+// (96 VGPRs, 5 waves/SIMD) although those re-read twice as many j-halo rows: the stage is bound by loads in flight per
+// wave, not by traffic -- a variant that shared the halo rows of a 16/32-row block tile through LDS (one barrier per
+// plane) cut the traffic and ran no faster, so it was dropped; the re-read rows are served by L2 / Infinity Cache.
+template <int JT>
+__global__ __launch_bounds__(256) void k_explicit_v5(const double *__restrict__ T, const uint8_t *__restrict__ flags,
+                                                     double *__restrict__ R0, Lay L, double invdx2, double f,
+                                                     int jslab, int ktiles, int ichunk, long ntiles, int i_begin,
+                                                     int i_end)
+{
+#pragma clang fp contract(off)
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
+    const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
+    // tile order: [slab][i-chunk][j-tile in slab][k-tile]
+    const int jt_per_slab = (jslab + JT - 1) / JT;
+    const int nchunk = (i_end - i_begin + ichunk - 1) / ichunk;
+    const long per_chunk = (long)jt_per_slab * ktiles;
+    const long per_slab = per_chunk * nchunk;
+    const unsigned t32 = (unsigned)tile, pch = (unsigned)per_chunk, psl = (unsigned)per_slab;
+    const int slab = (int)(t32 / psl);
+    unsigned rem = t32 - (unsigned)slab * psl;
+    const int ic = (int)(rem / pch);
+    rem -= (unsigned)ic * pch;
+    const int jt = (int)(rem / (unsigned)ktiles), kt = (int)(rem - (unsigned)jt * (unsigned)ktiles);
+    const int j0 = slab * jslab + jt * JT;
+    int jend = j0 + JT;
+    if (jend > (slab + 1) * jslab) jend = (slab + 1) * jslab;
+    if (jend > ny) jend = ny;
+    if (j0 >= jend) return;
+    const int i0 = i_begin + ic * ichunk;
+    const int i1 = (i0 + ichunk < i_end) ? i0 + ichunk : i_end;
+    const int k0 = kt * 512 + 2 * (int)threadIdx.x;
+    const bool kin = k0 < nz;
+    const int lane = threadIdx.x & 63;
+    const long sx = L.sx, sy = nz;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    const long pbase = (long)j0 * sy + k0;
+    // lane 0 / lane 63 fetch the value just outside the wave's k range (one load per row)
+    const bool edge = kin && ((lane == 0 && k0 > 0) || (lane == 63 && k0 + 2 < nz));
+    const long eoff = (lane == 0) ? -1 : 2;
+    const bool up = kin && j0 > 0, dn = kin && jend < ny;
+
+    double2 tm[JT], tc[JT], tp[JT], tq[JT];
+    unsigned fl[JT], fln[JT];
+    double ke[JT], ken[JT];
+    double2 hm = zero2, hp = zero2, hmn = zero2, hpn = zero2;
+    auto load_plane = [&](int i, double2 (&dst)[JT]) {
+#pragma unroll
+        for (int r = 0; r < JT; ++r) {
+            dst[r] = zero2;
+            if (kin && j0 + r < jend && i >= 0 && i < nx)
+                dst[r] = *reinterpret_cast<const double2 *>(T + (long)i * sx + pbase + (long)r * sy);
+        }
+    };
+    auto load_meta = [&](int i, unsigned (&F)[JT], double (&E)[JT], double2 &HM, double2 &HP) {
+        const long p = (long)i * sx + pbase;
+#pragma unroll
+        for (int r = 0; r < JT; ++r) {
+            F[r] = 0; E[r] = 0.0;
+            if (kin && j0 + r < jend) F[r] = *reinterpret_cast<const uint16_t *>(flags + p + (long)r * sy);
+            if (edge && j0 + r < jend) E[r] = T[p + (long)r * sy + eoff];
+        }
+        HM = zero2; HP = zero2;
+        if (up) HM = *reinterpret_cast<const double2 *>(T + p - sy);
+        if (dn) HP = *reinterpret_cast<const double2 *>(T + p + (long)(jend - j0) * sy);
+    };
+    load_plane(i0 - 1, tm);
+    load_plane(i0, tc);
+    load_plane(i0 + 1, tp);
+    load_meta(i0, fl, ke, hm, hp);
+    for (int i = i0; i < i1; ++i) {
+        const long p = (long)i * sx + pbase;
+        const bool more = i + 1 < i1;
+        if (more) {
+            load_plane(i + 2, tq);
+            load_meta(i + 1, fln, ken, hmn, hpn);
+        }
+#pragma unroll
+        for (int r = 0; r < JT; ++r) {
+            const bool rin = j0 + r < jend;
+            const long q = p + (long)r * sy;
+            double kl = __shfl_up(tc[r].y, 1), kr = __shfl_down(tc[r].x, 1);
+            if (lane == 0) kl = ke[r];
+            if (lane == 63) kr = ke[r];
+            const double2 jm = (r == 0) ? hm : tc[r > 0 ? r - 1 : 0];
+            const double2 jp = (j0 + r + 1 == jend) ? hp : tc[r + 1 < JT ? r + 1 : JT - 1];
+            const unsigned f0 = fl[r] & 0xffu, f1 = fl[r] >> 8;
+            double r0v, r1v;
+            {
+                double L0 = 0.0, L1 = 0.0, L2 = 0.0;
+                if (f0 & 1u) {
+                    L0 = lap_axis(f0 & 2u, f0 & 4u, tm[r].x, tp[r].x, tc[r].x, invdx2);
+                    L1 = lap_axis(f0 & 8u, f0 & 16u, jm.x, jp.x, tc[r].x, invdx2);
+                    L2 = lap_axis(f0 & 32u, f0 & 64u, kl, tc[r].y, tc[r].x, invdx2);
+                }
+                r0v = tc[r].x + f * ((L0 + L1) + L2);
+            }
+            {
+                double L0 = 0.0, L1 = 0.0, L2 = 0.0;
+                if (f1 & 1u) {
+                    L0 = lap_axis(f1 & 2u, f1 & 4u, tm[r].y, tp[r].y, tc[r].y, invdx2);
+                    L1 = lap_axis(f1 & 8u, f1 & 16u, jm.y, jp.y, tc[r].y, invdx2);
+                    L2 = lap_axis(f1 & 32u, f1 & 64u, tc[r].x, kr, tc[r].y, invdx2);
+                }
+                r1v = tc[r].y + f * ((L0 + L1) + L2);
+            }
+            if (kin && rin) *reinterpret_cast<double2 *>(R0 + q) = make_double2(r0v, r1v);
+        }
+#pragma unroll
+        for (int r = 0; r < JT; ++r) {
+            tm[r] = tc[r]; tc[r] = tp[r]; tp[r] = tq[r];
+            fl[r] = fln[r]; ke[r] = ken[r];
+        }
+        hm = hmn; hp = hpn;
     }
 }
 
@@ -1703,8 +1824,24 @@ int adi_explicit_rhs_planes(const double *d_T, const uint8_t *d_flags, int nx, i
     const bool fast = (nz % 2 == 0) && (L.sx % 2 == 0) && ((((uintptr_t)d_T | (uintptr_t)d_R0) & 15) == 0) &&
                       (((uintptr_t)d_flags & 1) == 0);
     static int ver = 0;
-    if (ver == 0) { const char *e = getenv("ADI_EXPLICIT_VER"); ver = e ? atoi(e) : 3; }
-    if (fast && (ver == 3 || np != nx)) {
+    if (ver == 0) { const char *e = getenv("ADI_EXPLICIT_VER"); ver = e ? atoi(e) : 5; }
+    if (fast && ver >= 4) {
+        const int jslab = (ny + 7) / 8;
+        const int nslab = (ny + jslab - 1) / jslab;
+        const int ktiles = (nz + 511) / 512;
+        int ichunk = np >= 512 ? 32 : (np / 16 < 4 ? 4 : np / 16);
+        { const char *e = getenv("ADI_EXPLICIT_ICHUNK"); if (e && atoi(e) >= 1) ichunk = atoi(e); }
+        const int nchunk = (np + ichunk - 1) / ichunk;
+        static int jt5 = 0;
+        if (jt5 == 0) { const char *e = getenv("ADI_EXPLICIT_JT"); jt5 = (e && atoi(e) == 4) ? 4 : 2; }
+        const long ntiles = (long)nslab * nchunk * ((jslab + jt5 - 1) / jt5) * ktiles;
+        if (jt5 == 2)
+            hipLaunchKernelGGL(k_explicit_v5<2>, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
+                               L, invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end);
+        else
+            hipLaunchKernelGGL(k_explicit_v5<4>, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
+                               L, invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end);
+    } else if (fast && (ver == 3 || np != nx)) {
         const int jslab = (ny + 7) / 8;
         const int nslab = (ny + jslab - 1) / jslab;
         const int ktiles = (nz + 511) / 512;
@@ -1713,9 +1850,15 @@ int adi_explicit_rhs_planes(const double *d_T, const uint8_t *d_flags, int nx, i
         int ichunk = np >= 512 ? 32 : (np / 16 < 4 ? 4 : np / 16);
         { const char *e = getenv("ADI_EXPLICIT_ICHUNK"); if (e && atoi(e) >= 1) ichunk = atoi(e); }
         const int nchunk = (np + ichunk - 1) / ichunk;
-        const long ntiles = (long)nslab * nchunk * ((jslab + JT3 - 1) / JT3) * ktiles;
-        hipLaunchKernelGGL(k_explicit_v3, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0, L,
-                           invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end);
+        static int jt = 0;
+        if (jt == 0) { const char *e = getenv("ADI_EXPLICIT_JT"); jt = (e && atoi(e) == 8) ? 8 : 4; }
+        const long ntiles = (long)nslab * nchunk * ((jslab + jt - 1) / jt) * ktiles;
+        if (jt == 8)
+            hipLaunchKernelGGL(k_explicit_v3<8>, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
+                               L, invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end);
+        else
+            hipLaunchKernelGGL(k_explicit_v3<4>, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
+                               L, invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end);
     } else if (fast) {
         const int jslab = (ny + 7) / 8;
         const int nslab = (ny + jslab - 1) / jslab;
