@@ -55,6 +55,13 @@ SIGNATURES = {
     'adi_sweep_condense': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    'adi_explicit_fused_supported': (c_int, [c_int, c_int, c_int, c_long, c_int]),
+    'adi_explicit_sweep0': (c_int, [c_int, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double, c_double,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'adi_explicit_condense0': (c_int, [c_int, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double,
+                                       c_double, c_void_p, c_void_p, c_size_t, c_void_p]),
     'adi_interface_solve': (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
     'adi_interface_pair': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     'adi_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_pp, c_void_p, c_void_p,

@@ -444,6 +444,41 @@ def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None, 
                         _p(work), wb, _stream()))
 
 
+def fused_supported(grid, cond_pass=False):
+    """explicit stage folded into the axis-0 sweep (adi_explicit_sweep0, ABI v7) available for this grid"""
+    return bool(lib.adi_explicit_fused_supported(grid.nx, grid.ny, grid.nz, grid.sx, 1 if cond_pass else 0))
+
+
+def valid_range(t):
+    """element offsets relative to t's first element that lie inside its storage: the [valid_lo, valid_hi) of
+    adi_explicit_sweep0 / adi_explicit_condense0"""
+    off = t.storage_offset()
+    return -off, t.untyped_storage().nbytes() // t.element_size() - off
+
+
+def _explicit_sweep0_into(t, t_out, grid, mat, params, pack, Tinf, variant=None, dense=False):
+    """stages 1+2 of adi_step_numba_coeff (adi3d_numba_coeff.py:292-299) in one pass: R0 is evaluated inside the
+    loads of the axis-0 sweep.  Neighbours are read anywhere inside t's storage."""
+    kappa, _ = _gam(grid, mat, params)
+    _, work, wb = grid.scratch(2)
+    v = pack.variant if variant is None else variant
+    vlo, vhi = valid_range(t)
+    check(lib.adi_explicit_sweep0(v, _p(t), vlo, vhi, _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
+                                  _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
+                                  int(pack.sparse_ok and not dense), grid.dx, params.dt, kappa, params.theta,
+                                  float(Tinf), _p(t_out), None, None, _p(work), wb, _stream()))
+
+
+def adi_explicit_sweep_axis0(Tn, grid, mat, params, pack, Tinf=0.0, variant=None, dense=False):
+    """U of adi3d_numba_coeff.py:299 straight from Tn (stage entry point of the fused kernel)."""
+    t, kind = _as_state(Tn, grid)
+    if variant == _lib.SWEEP_GENERAL or (variant is None and pack.variant == _lib.SWEEP_GENERAL):
+        _ensure_general(pack)
+    out = grid.layout.empty()
+    _explicit_sweep0_into(t, out, grid, mat, params, pack, Tinf, variant, dense)
+    return _wrap(out, kind)
+
+
 def adi_sweep_axis(axis, stage_in, grid, mat, params, pack, Tinf=0.0, variant=None, dense=False):
     """sweep_axis0/1/2 of adi3d_numba_coeff.py:133-237 for one axis (stage entry point).
     variant=None picks the leanest kernel the pack allows; variant=_lib.SWEEP_GENERAL with dense=True forces
@@ -476,9 +511,12 @@ def adi_step_hip_coeff(Tn, grid, mat, params, packs, Tinf=0.0):
     (ta, tb), _, _ = grid.scratch(2)
     kappa, _ = _gam(grid, mat, params)
     out = grid.layout.empty()
-    check(lib.adi_explicit_rhs(_p(t), _p(grid.d_flags), grid.nx, grid.ny, grid.nz, grid.sx, grid.dx, params.dt,
-                               kappa, params.theta, _p(ta), _stream()))
-    _sweep_into(0, ta, tb, grid, mat, params, packx, Tinf)
+    if fused_supported(grid):
+        _explicit_sweep0_into(t, tb, grid, mat, params, packx, Tinf)
+    else:
+        check(lib.adi_explicit_rhs(_p(t), _p(grid.d_flags), grid.nx, grid.ny, grid.nz, grid.sx, grid.dx, params.dt,
+                                   kappa, params.theta, _p(ta), _stream()))
+        _sweep_into(0, ta, tb, grid, mat, params, packx, Tinf)
     _sweep_into(1, tb, ta, grid, mat, params, packy, Tinf)
     _sweep_into(2, ta, out, grid, mat, params, packz, Tinf)
     return _wrap(out, kind)
@@ -514,11 +552,17 @@ class StagedStepper:
     quick_compare_dirichlet_robin.py:169-178).  `events`: optional list of 5 torch.cuda.Event recorded on
     the launch stream before/between/after the four stage kernels (per-stage HIP-event timing)."""
 
-    stage_names = ['explicit', 'sweep_axis0', 'sweep_axis1', 'sweep_axis2_contig']
-
-    def __init__(self, grid, mat, params, packs, Tinf=0.0):
+    def __init__(self, grid, mat, params, packs, Tinf=0.0, fused=None):
         self.grid, self.mat, self.params, self.packs, self.Tinf = grid, mat, params, packs, float(Tinf)
-        self.stage_bytes_per_cell = [float(_lib.EXPLICIT_BYTES_PER_CELL)] + [p.bytes_per_cell for p in packs]
+        self.fused = fused_supported(grid) if fused is None else (bool(fused) and fused_supported(grid))
+        if self.fused:
+            # the fused kernel reads T + flags (+ the pack arrays of the axis-0 sweep) and writes U: the sweep's own
+            # byte count (SURVEY.md 8(d) variant rule); R0 never reaches HBM
+            self.stage_names = ['explicit+sweep_axis0', 'sweep_axis1', 'sweep_axis2_contig']
+            self.stage_bytes_per_cell = [p.bytes_per_cell for p in packs]
+        else:
+            self.stage_names = ['explicit', 'sweep_axis0', 'sweep_axis1', 'sweep_axis2_contig']
+            self.stage_bytes_per_cell = [float(_lib.EXPLICIT_BYTES_PER_CELL)] + [p.bytes_per_cell for p in packs]
 
     def sweep_into(self, axis, t_in, t_out, variant=None, dense=False):
         if variant == _lib.SWEEP_GENERAL:
@@ -532,19 +576,24 @@ class StagedStepper:
         (ta, tb), _, _ = g.scratch(2)
         kappa, _ = _gam(g, self.mat, prm)
         out = g.layout.empty()
-        if events is not None:
-            events[0].record()
-        check(lib.adi_explicit_rhs(_p(t), _p(g.d_flags), g.nx, g.ny, g.nz, g.sx, g.dx, prm.dt, kappa, prm.theta,
-                                   _p(ta), _stream()))
-        if events is not None:
-            events[1].record()
-        self.sweep_into(0, ta, tb)
-        if events is not None:
-            events[2].record()
+        ne = 0
+
+        def mark():
+            nonlocal ne
+            if events is not None:
+                events[ne].record()
+            ne += 1
+        mark()
+        if self.fused:
+            _explicit_sweep0_into(t, tb, g, self.mat, prm, self.packs[0], self.Tinf)
+        else:
+            check(lib.adi_explicit_rhs(_p(t), _p(g.d_flags), g.nx, g.ny, g.nz, g.sx, g.dx, prm.dt, kappa, prm.theta,
+                                       _p(ta), _stream()))
+            mark()
+            self.sweep_into(0, ta, tb)
+        mark()
         self.sweep_into(1, tb, ta)
-        if events is not None:
-            events[3].record()
+        mark()
         self.sweep_into(2, ta, out)
-        if events is not None:
-            events[4].record()
+        mark()
         return DeviceField(out)

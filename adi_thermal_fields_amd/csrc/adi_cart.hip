@@ -41,6 +41,53 @@ __device__ __forceinline__ bool axis_exposed(unsigned f, int lbit)
     return (f & 1u) && (((f >> lbit) & 3u) != 3u);
 }
 
+// One axis of lap1D_x/y/z (adi3d_numba_coeff.py:240-288) in the reference's evaluation order.
+__device__ __forceinline__ double lap_axis(bool lo, bool hi, double tlo, double thi, double t, double invdx2)
+{
+#pragma clang fp contract(off)
+    double sacc = 0.0, cnt = 0.0;   // s = 0; if lower in mask: s += T_lo; c += 1; ... (adi3d_numba_coeff.py:246-253)
+    if (lo) { sacc += tlo; cnt += 1.0; }
+    if (hi) { sacc += thi; cnt += 1.0; }
+    return (sacc - cnt * t) * invdx2;
+}
+
+// Explicit stage folded into the loads of the axis-0 sweep (FUSE kernels): `in` is the state T, and the value a
+// row feeds into its right-hand side is R0 = T + f*(Lx+Ly+Lz) (adi3d_numba_coeff.py:292-298) computed on the fly
+// from the six neighbours -- i-neighbours are the thread's own adjacent rows, k-neighbours sit in the adjacent
+// lanes, j-neighbours are re-read (L2 / Infinity Cache serves them: the tile that owns them runs next door).
+// [vlo, vhi): element offsets relative to `in` that may be read (the whole buffer the view lives in, halo planes
+// of a slab included); the FAST kernel loads neighbours without waiting for the flags and needs the bound, the
+// GENERAL kernel loads a neighbour only where the flags byte says it exists.
+struct Fuse {
+    double invdx2, f;
+    long sy;
+    long vlo, vhi;
+    int kt, ny, kg;     // FAST kernel tile order: kt tiles per j-row, groups of kg k-tiles walked j-fastest (kg = 0: off)
+};
+
+// FUSE tile order: the j-neighbour rows a tile re-reads belong to the tiles of the adjacent j-rows; walking groups of kg
+// k-tiles j-fastest puts those tiles on the same XCD at the same time, so the re-reads are L2 hits.
+__device__ __forceinline__ long tile_jfast(long t, const Fuse &z)
+{
+    const unsigned per = (unsigned)z.ny * (unsigned)z.kg;
+    const unsigned hi = (unsigned)t / per, r = (unsigned)t - hi * per;
+    const unsigned j = r / (unsigned)z.kg, lo = r - j * (unsigned)z.kg;
+    return (long)j * z.kt + (long)hi * z.kg + lo;
+}
+
+__device__ __forceinline__ double explicit_cell(unsigned fl, double t, double im, double ip, double jm, double jp,
+                                                double km, double kp, const Fuse &z)
+{
+#pragma clang fp contract(off)
+    double L0 = 0.0, L1 = 0.0, L2 = 0.0;
+    if (fl & 1u) {
+        L0 = lap_axis(fl & 2u, fl & 4u, im, ip, t, z.invdx2);
+        L1 = lap_axis(fl & 8u, fl & 16u, jm, jp, t, z.invdx2);
+        L2 = lap_axis(fl & 32u, fl & 64u, km, kp, t, z.invdx2);
+    }
+    return t + z.f * ((L0 + L1) + L2);
+}
+
 // Assemble one row of the full-length system (adi3d_gpu_coeff.py:173-187; numba form :147-162).
 //   m / mL / mR : cell, previous and next cell of the line are in the mask
 //   off-mask    : identity row keeping the incoming value
@@ -425,11 +472,11 @@ struct SegRaw {
     bool dirb[M];
 };
 
-template <int M, bool HAS_DIR, bool HAS_Q>
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
 __device__ __forceinline__ void load_segment_raw(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    const LineGeom &g, long base, int r0, bool active, const SweepScal &s, SegRaw<M> &R)
+    const LineGeom &g, long base, int r0, bool active, const SweepScal &s, SegRaw<M> &R, const Fuse &fz = Fuse())
 {
 #pragma unroll
     for (int r = 0; r < M; ++r) {
@@ -437,6 +484,25 @@ __device__ __forceinline__ void load_segment_raw(
         const long p = base + (long)(r0 + r) * g.stride;
         R.fb[r] = ok ? flags[p] : 0u;
         R.vin[r] = ok ? in[p] : 0.0;
+    }
+    if (FUSE) {
+        // vin <- R0 of the explicit stage; every neighbour is loaded only where the flags byte says it exists
+        // (rows beyond the line / inactive lanes have flags 0 and stay 0)
+        double prev = 0.0;
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            const long p = base + (long)(r0 + r) * g.stride;
+            const unsigned f = R.fb[r];
+            const double cur = R.vin[r];
+            double im, ip;
+            if (r > 0) im = prev; else im = (f & 2u) ? in[p - g.stride] : 0.0;
+            if (r < M - 1 && r0 + r + 1 < g.n) ip = R.vin[r + 1];   // still the state: rows are overwritten in order
+            else ip = (f & 4u) ? in[p + g.stride] : 0.0;             // next segment / halo plane of a slab
+            const double jm = (f & 8u) ? in[p - fz.sy] : 0.0, jp = (f & 16u) ? in[p + fz.sy] : 0.0;
+            const double km = (f & 32u) ? in[p - 1] : 0.0, kp = (f & 64u) ? in[p + 1] : 0.0;
+            R.vin[r] = explicit_cell(f, cur, im, ip, jm, jp, km, kp, fz);
+            prev = cur;
+        }
     }
 #pragma unroll
     for (int r = 0; r < M; ++r) {
@@ -498,12 +564,13 @@ __device__ __forceinline__ void tile_separators(double *sm, int tid, int kk, int
     xL = (sg > 0) ? sXS[kk * ld + sg - 1] : 0.0;
 }
 
-template <int M, bool HAS_DIR, bool HAS_Q>
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
 __device__ __forceinline__ void strided_tile_general(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ out, const LineGeom &g, int Lp, int LINES, int tiles_inner, long tile,
-    const double *__restrict__ xlo, const double *__restrict__ xhi, const SweepScal &s, double *sm)
+    const double *__restrict__ xlo, const double *__restrict__ xhi, const SweepScal &s, double *sm,
+    const Fuse &fz = Fuse())
 {
     const int tid = threadIdx.x;
     const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
@@ -518,7 +585,7 @@ __device__ __forceinline__ void strided_tile_general(
     double a[M], b[M], c[M], d[M];
     {
         SegRaw<M> R;
-        load_segment_raw<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R);
+        load_segment_raw<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R, fz);
 #pragma unroll
         for (int r = 0; r < M; ++r) assemble_one<M, HAS_DIR, HAS_Q>(R, r, g.lbit, s, a[r], b[r], c[r], d[r]);
     }
@@ -546,18 +613,18 @@ __device__ __forceinline__ void strided_tile_general(
 }
 
 // GENERAL kernel: every tile (queue == nullptr) or the tiles a FAST kernel queued
-template <int M, bool HAS_DIR, bool HAS_Q>
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
 __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ out, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
     const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s, const unsigned *__restrict__ queue,
-    int ratio, int tiles_inner_f)
+    int ratio, int tiles_inner_f, Fuse fz)
 {
     extern __shared__ __align__(16) double sm[];
     if (queue == nullptr) {
-        strided_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, Lp, LINES, tiles_inner,
-                                                xcd_chunk_tile(blockIdx.x, ntiles), xlo, xhi, s, sm);
+        strided_tile_general<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, out, g, Lp, LINES, tiles_inner,
+                                                      xcd_chunk_tile(blockIdx.x, ntiles), xlo, xhi, s, sm, fz);
     } else {
         // a queued unit is a tile of the FAST kernel = `ratio` adjacent tiles of this kernel
         const long cnt = (long)queue[0] * ratio;
@@ -566,8 +633,8 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
             const long to = (long)((unsigned)u / (unsigned)tiles_inner_f);
             const long tig = (u - to * tiles_inner_f) * ratio + ((unsigned)i % (unsigned)ratio);
             if (tig < tiles_inner)
-                strided_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, g, Lp, LINES, tiles_inner,
-                                                        to * tiles_inner + tig, xlo, xhi, s, sm);
+                strided_tile_general<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, out, g, Lp, LINES,
+                                                              tiles_inner, to * tiles_inner + tig, xlo, xhi, s, sm, fz);
             __syncthreads();   // the LDS arrays are reused by the next tile
         }
     }
@@ -605,6 +672,116 @@ __device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in_
     return lane_fast;
 }
 
+// The same with the explicit stage folded in (FUSE kernels): d <- R0 = T + f*(Lx+Ly+Lz) of this thread's M rows.
+// Preconditions (block-uniform, checked by the caller): the tile is whole -- LINES == 16 active lines, every thread owns
+// M rows of the line (Lp*M == n) -- so no load needs a per-row predicate.  Neighbour loads do not wait for the flags:
+// an address is read whenever it lies inside [vlo, vhi) and the value is used only where the flags byte says the
+// neighbour exists; only the first row of a line can fall below vlo and only the last row above vhi.
+// A 16-lane DPP row = the 16 lines of one segment: k-neighbours come from the adjacent lanes (row_shr/row_shl), the two
+// outside the tile are loaded transposed (lane kk fetches the pair of row kk) and handed to lanes 0 / 15 with
+// row_newbcast as the `old` operand of the shift, which is what the out-of-row lane keeps.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double old, double src)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// value of lane r of every 16-lane row, in all lanes of that row (DPP row_newbcast:r)
+__device__ __forceinline__ double row_bcast(double v, int r)
+{
+    switch (r & 15) {
+#define ADI_BC(n) case n: return dpp_mov<0x150 + n>(0.0, v);
+        ADI_BC(0) ADI_BC(1) ADI_BC(2) ADI_BC(3) ADI_BC(4) ADI_BC(5) ADI_BC(6) ADI_BC(7)
+        ADI_BC(8) ADI_BC(9) ADI_BC(10) ADI_BC(11) ADI_BC(12) ADI_BC(13) ADI_BC(14)
+#undef ADI_BC
+        default: return dpp_mov<0x15f>(0.0, v);
+    }
+}
+
+template <int M, bool HAS_DIR>
+__device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict__ in_t,
+                                                        const uint8_t *__restrict__ flags_t,
+                                                        const uint8_t *__restrict__ dmask_t, const LineGeom &g,
+                                                        unsigned voff, int r0, int kk, long tbase, const Fuse &fz,
+                                                        double (&d)[M], unsigned &f0, unsigned &fS, bool &dirS)
+{
+#pragma clang fp contract(off)
+    constexpr int LINES = 16;
+    const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
+    unsigned fb[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        fb[r] = (flags_t + (size_t)r * g.stride)[voff];
+        d[r] = (in_t + (size_t)r * g.stride)[voff];
+    }
+    const long p0 = tbase + (long)voff;                     // offset of this thread's row 0 relative to `in`
+    const bool first = r0 == 0, last = r0 + M >= g.n;
+    const long pl = p0 + (long)(M - 1) * g.stride;
+    double tim = 0.0, tip = 0.0;
+    if (!first || p0 - g.stride >= fz.vlo) tim = (in_t - (size_t)g.stride)[voff];
+    if (!last || pl + g.stride < fz.vhi) tip = (in_t + (size_t)M * g.stride)[voff];
+    double eL = 0.0, eR = 0.0;
+    if (kk < M) {
+        const long pe = tbase + (long)(r0 + kk) * g.stride;
+        const double *rowe = in_t + (size_t)(r0 + kk) * g.stride;
+        if (pe - 1 >= fz.vlo) eL = rowe[-1];
+        if (pe + LINES < fz.vhi) eR = rowe[LINES];
+    }
+    bool lane_fast = true, full = true;
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        full = full && (fb[r] == 0x7fu);
+        if (r == 0) lane_fast = lane_fast && ((fb[r] & ROW0) == ROW0);
+        else if (r < M - 1) lane_fast = lane_fast && ((fb[r] & FULL) == FULL);
+    }
+    f0 = fb[0]; fS = fb[M - 1];
+    const bool wave_full = __all(full);                     // every cell of this wave has its six neighbours
+    const double two_inv = fz.invdx2;
+    double prev = tim;
+    constexpr int H = (M >= 8) ? M / 2 : M;                 // j-halo rows in flight at once (register budget)
+#pragma unroll
+    for (int h = 0; h < M / H; ++h) {
+        double jm[H], jp[H];
+#pragma unroll
+        for (int q = 0; q < H; ++q) {
+            const int r = h * H + q;
+            const double *row = in_t + (size_t)r * g.stride;
+            jm[q] = 0.0; jp[q] = 0.0;
+            if (r > 0 || !first || p0 - fz.sy >= fz.vlo) jm[q] = (row - fz.sy)[voff];
+            if (r < M - 1 || !last || pl + fz.sy < fz.vhi) jp[q] = (row + fz.sy)[voff];
+        }
+#pragma unroll
+        for (int q = 0; q < H; ++q) {
+            const int r = h * H + q;
+            const double cur = d[r];
+            const double nxt = (r < M - 1) ? d[r + 1] : tip;     // still the state: rows are overwritten in order
+            const double el = row_bcast(eL, r), er = row_bcast(eR, r);
+            const double km = dpp_mov<0x111>(el, cur), kp = dpp_mov<0x101>(er, cur);
+            if (wave_full) {
+                // lap_axis with both neighbours present, same operation order: ((0 + lo) + hi - 2*t) * invdx2
+                const double c2 = 2.0 * cur;
+                const double L0 = (((0.0 + prev) + nxt) - c2) * two_inv;
+                const double L1 = (((0.0 + jm[q]) + jp[q]) - c2) * two_inv;
+                const double L2 = (((0.0 + km) + kp) - c2) * two_inv;
+                d[r] = cur + fz.f * ((L0 + L1) + L2);
+            } else {
+                d[r] = explicit_cell(fb[r], cur, prev, nxt, jm[q], jp[q], km, kp, fz);
+            }
+            prev = cur;
+        }
+    }
+    dirS = false;
+    if (HAS_DIR) {
+#pragma unroll
+        for (int r = 0; r < M - 1; ++r)
+            lane_fast = lane_fast && ((dmask_t + (size_t)r * g.stride)[voff] == 0);
+        dirS = (dmask_t + (size_t)(M - 1) * g.stride)[voff] != 0;
+    }
+    return lane_fast;
+}
+
 // part 2: the two general rows of a uniform segment (row 0 and the separator)
 template <int M, bool HAS_DIR, bool HAS_Q>
 __device__ __forceinline__ void fast_segment_ends(const double *__restrict__ coeff, const double *__restrict__ dval,
@@ -627,17 +804,18 @@ __device__ __forceinline__ void fast_segment_ends(const double *__restrict__ coe
 }
 
 // FAST kernel (sparse packs): tiles whose every segment is uniform-interior (see k_sweep_contig_fast)
-template <int M, bool HAS_DIR, bool HAS_Q>
-__global__ __launch_bounds__(512) void k_sweep_strided_fast(
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
+__global__ __launch_bounds__(512, FUSE ? 4 : 1) void k_sweep_strided_fast(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ out, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
     const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s, unsigned *__restrict__ queue,
-    UniC<M> U)
+    UniC<M> U, Fuse fz)
 {
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x;
-    const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
+    long tile = xcd_chunk_tile(blockIdx.x, ntiles);
+    if (FUSE && fz.kg > 0) tile = tile_jfast(tile, fz);
     const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
     const int ti = (int)(tile - to * tiles_inner);
     const int kk = tid & (LINES - 1), sg = tid >> (__ffs(LINES) - 1);   // LINES is a power of two
@@ -653,8 +831,19 @@ __global__ __launch_bounds__(512) void k_sweep_strided_fast(
     // block-uniform tile base (scalar) + one 32-bit per-thread offset for every row of every array
     const long tbase = to * g.outer_stride + (long)ti * LINES;
     const unsigned voff = (unsigned)((long)r0 * g.stride + kk);
-    const bool lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g,
-                                                         voff, r0, active, d, f0, fS, dirS);
+    bool lane_fast;
+    if constexpr (FUSE) {
+        // whole tiles only (block-uniform): anything else goes to the GENERAL kernel before a single load is issued
+        if (LINES != 16 || (ti + 1) * LINES > g.n_inner || Lp * M != g.n) {
+            if (tid == 0) enqueue_unit(queue, (unsigned)tile);
+            return;
+        }
+        lane_fast = fast_segment_load_fused<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff,
+                                                        r0, kk, tbase, fz, d, f0, fS, dirS);
+    } else {
+        lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
+                                                  active, d, f0, fS, dirS);
+    }
     if (!__syncthreads_and(lane_fast)) {
         if (tid == 0) enqueue_unit(queue, (unsigned)tile);
         return;
@@ -714,12 +903,12 @@ __device__ __forceinline__ void tile_reduce_store(double *sm, int tid, int kk, i
     }
 }
 
-template <int M, bool HAS_DIR, bool HAS_Q>
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
 __device__ __forceinline__ void condense_tile_general(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ cond, long nlines, const LineGeom &g, int Lp, int LINES, int tiles_inner, long tile,
-    const SweepScal &s, double *sm)
+    const SweepScal &s, double *sm, const Fuse &fz = Fuse())
 {
     const int tid = threadIdx.x;
     const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
@@ -734,7 +923,7 @@ __device__ __forceinline__ void condense_tile_general(
         // same assembly as the solve pass, but the end couplings stay in a[0] / c[n-1] (they are the
         // aF, aL / cF, cL of the slab)
         SegRaw<M> R;
-        load_segment_raw<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R);
+        load_segment_raw<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R, fz);
 #pragma unroll
         for (int r = 0; r < M; ++r) assemble_one<M, HAS_DIR, HAS_Q>(R, r, g.lbit, s, a[r], b[r], c[r], d[r]);
     }
@@ -743,17 +932,17 @@ __device__ __forceinline__ void condense_tile_general(
     tile_reduce_store(sm, tid, kk, sg, Lp, LINES, k, g.n / M, to, ti, g, nlines, cond);
 }
 
-template <int M, bool HAS_DIR, bool HAS_Q>
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
 __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_condense_strided(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ cond, long nlines, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
-    SweepScal s, const unsigned *__restrict__ queue, int ratio, int tiles_inner_f)
+    SweepScal s, const unsigned *__restrict__ queue, int ratio, int tiles_inner_f, Fuse fz)
 {
     extern __shared__ __align__(16) double sm[];
     if (queue == nullptr) {
-        condense_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, LINES,
-                                                 tiles_inner, xcd_chunk_tile(blockIdx.x, ntiles), s, sm);
+        condense_tile_general<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, LINES,
+                                                       tiles_inner, xcd_chunk_tile(blockIdx.x, ntiles), s, sm, fz);
     } else {
         const long cnt = (long)queue[0] * ratio;
         for (long i = blockIdx.x; i < cnt; i += gridDim.x) {
@@ -761,8 +950,8 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_condense_strided(
             const long to = (long)((unsigned)u / (unsigned)tiles_inner_f);
             const long tig = (u - to * tiles_inner_f) * ratio + ((unsigned)i % (unsigned)ratio);
             if (tig < tiles_inner)
-                condense_tile_general<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, LINES,
-                                                         tiles_inner, to * tiles_inner + tig, s, sm);
+                condense_tile_general<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp,
+                                                               LINES, tiles_inner, to * tiles_inner + tig, s, sm, fz);
             __syncthreads();
         }
     }
@@ -770,16 +959,17 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_condense_strided(
 
 // FAST pass A: uniform-interior segments (see k_sweep_strided_fast); the block of a thread = its M-1 uniform
 // interior rows merged with its general separator row.
-template <int M, bool HAS_DIR, bool HAS_Q>
-__global__ __launch_bounds__(512) void k_condense_strided_fast(
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
+__global__ __launch_bounds__(512, FUSE ? 4 : 1) void k_condense_strided_fast(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ cond, long nlines, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
-    SweepScal s, unsigned *__restrict__ queue, UniC<M> U)
+    SweepScal s, unsigned *__restrict__ queue, UniC<M> U, Fuse fz)
 {
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x;
-    const long tile = xcd_chunk_tile(blockIdx.x, ntiles);
+    long tile = xcd_chunk_tile(blockIdx.x, ntiles);
+    if (FUSE && fz.kg > 0) tile = tile_jfast(tile, fz);
     const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
     const int ti = (int)(tile - to * tiles_inner);
     const int kk = tid & (LINES - 1), sg = tid >> (__ffs(LINES) - 1);   // LINES is a power of two
@@ -794,8 +984,19 @@ __global__ __launch_bounds__(512) void k_condense_strided_fast(
     // block-uniform tile base (scalar) + one 32-bit per-thread offset for every row of every array
     const long tbase = to * g.outer_stride + (long)ti * LINES;
     const unsigned voff = (unsigned)((long)r0 * g.stride + kk);
-    const bool lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g,
-                                                         voff, r0, active, d, f0, fS, dirS);
+    bool lane_fast;
+    if constexpr (FUSE) {
+        // whole tiles only (block-uniform): anything else goes to the GENERAL kernel before a single load is issued
+        if (LINES != 16 || (ti + 1) * LINES > g.n_inner || Lp * M != g.n) {
+            if (tid == 0) enqueue_unit(queue, (unsigned)tile);
+            return;
+        }
+        lane_fast = fast_segment_load_fused<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff,
+                                                        r0, kk, tbase, fz, d, f0, fS, dirS);
+    } else {
+        lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
+                                                  active, d, f0, fS, dirS);
+    }
     if (!__syncthreads_and(lane_fast)) {
         if (tid == 0) enqueue_unit(queue, (unsigned)tile);
         return;
@@ -974,14 +1175,6 @@ __global__ __launch_bounds__(256) void k_sweep_generic(
 // plane, so the i+-1 planes of a slab (3 x 256 KiB at 512^2) stay in that XCD's 4 MiB L2 and HBM sees each
 // T line once.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double lap_axis(bool lo, bool hi, double tlo, double thi, double t, double invdx2)
-{
-#pragma clang fp contract(off)
-    double sacc = 0.0, cnt = 0.0;   // s = 0; if lower in mask: s += T_lo; c += 1; ... (adi3d_numba_coeff.py:246-253)
-    if (lo) { sacc += tlo; cnt += 1.0; }
-    if (hi) { sacc += thi; cnt += 1.0; }
-    return (sacc - cnt * t) * invdx2;
-}
 
 static int explicit_jr()
 {
@@ -1598,71 +1791,92 @@ static StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok)
     return P;
 }
 
-template <int MF, bool HAS_DIR, bool HAS_Q>
+// the fused FAST kernels shuffle k-neighbours inside 16-lane DPP rows: 16 lines per tile, at most 16 rows per thread
+static bool fuse_fast_ok(const StridedPlan &P) { return P.Mf != 0 && P.lines_f == 16 && P.Mf <= 16; }
+
+static void fuse_tile_order(Fuse &fz, const StridedPlan &P, const Lay &L)
+{
+    static int kg = -1;
+    if (kg < 0) { const char *e = getenv("ADI_FUSE_KG"); kg = e ? atoi(e) : 4; if (kg < 0 || (kg & (kg - 1))) kg = 4; }
+    fz.kt = 0; fz.ny = L.ny; fz.kg = 0;
+    if (P.Mf != 0 && kg > 0 && L.nz % P.lines_f == 0) {
+        const int kt = L.nz / P.lines_f;
+        int k2 = kg;
+        while (k2 > 1 && kt % k2 != 0) k2 >>= 1;
+        fz.kt = kt; fz.kg = k2;          // tiles_inner_f == ny * kt: the remap is a permutation of the tile ids
+    }
+}
+
+template <int MF, bool HAS_DIR, bool HAS_Q, bool FUSE>
 static void launch_strided_fast(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
                                 const uint8_t *dmask, const double *dval, const double *qf, double *out,
                                 const LineGeom &g, const double *xlo, const double *xhi, SweepScal s, unsigned *queue,
-                                hipStream_t st)
+                                hipStream_t st, const Fuse &fz)
 {
-    hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q>), dim3((unsigned)P.ntiles_f), dim3(P.lines_f * P.Lpf),
-                       P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f, P.tiles_inner_f,
-                       P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg));
+    hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE>), dim3((unsigned)P.ntiles_f),
+                       dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
+                       P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
 }
 
-template <int M, bool HAS_DIR, bool HAS_Q>
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE>
 static void launch_strided(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
                            const uint8_t *dmask, const double *dval, const double *qf, double *out, const LineGeom &g,
-                           const double *xlo, const double *xhi, SweepScal s, unsigned *queue, hipStream_t st)
+                           const double *xlo, const double *xhi, SweepScal s, unsigned *queue, hipStream_t st,
+                           const Fuse &fz)
 {
     unsigned ggrid = (unsigned)P.ntiles_g;
     if (queue != nullptr) {
         (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
-        if (P.Mf == 32) launch_strided_fast<32, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st);
-        else if (P.Mf == 16) launch_strided_fast<16, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st);
-        else launch_strided_fast<8, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st);
+        if (P.Mf == 32) launch_strided_fast<32, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
+        else if (P.Mf == 16) launch_strided_fast<16, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
+        else launch_strided_fast<8, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         ggrid = P.ntiles_g < 1024 ? (unsigned)P.ntiles_g : 1024u;
     }
-    hipLaunchKernelGGL((k_sweep_strided<M, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(P.lines_g * P.Lpg), P.lds_g, st, in,
+    hipLaunchKernelGGL((k_sweep_strided<M, HAS_DIR, HAS_Q, FUSE>), dim3(ggrid), dim3(P.lines_g * P.Lpg), P.lds_g, st, in,
                        flags, coeff, dmask, dval, qf, out, g, P.Lpg, P.lines_g, P.tiles_inner_g, P.ntiles_g, xlo, xhi,
-                       s, queue, P.ratio, P.tiles_inner_f);
+                       s, queue, P.ratio, P.tiles_inner_f, fz);
 }
 
-template <int MF, bool HAS_DIR, bool HAS_Q>
+template <int MF, bool HAS_DIR, bool HAS_Q, bool FUSE>
 static void launch_condense_fast(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
                                  const uint8_t *dmask, const double *dval, const double *qf, double *cond, long nlines,
-                                 const LineGeom &g, SweepScal s, unsigned *queue, hipStream_t st)
+                                 const LineGeom &g, SweepScal s, unsigned *queue, hipStream_t st, const Fuse &fz)
 {
-    hipLaunchKernelGGL((k_condense_strided_fast<MF, HAS_DIR, HAS_Q>), dim3((unsigned)P.ntiles_f),
+    hipLaunchKernelGGL((k_condense_strided_fast<MF, HAS_DIR, HAS_Q, FUSE>), dim3((unsigned)P.ntiles_f),
                        dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, cond, nlines, g, P.Lpf,
-                       P.lines_f, P.tiles_inner_f, P.ntiles_f, s, queue, make_unic<MF>(s.tg));
+                       P.lines_f, P.tiles_inner_f, P.ntiles_f, s, queue, make_unic<MF>(s.tg), fz);
 }
 
-template <int M, bool HAS_DIR, bool HAS_Q>
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE>
 static void launch_condense(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
                             const uint8_t *dmask, const double *dval, const double *qf, double *cond, long nlines,
-                            const LineGeom &g, SweepScal s, unsigned *queue, hipStream_t st)
+                            const LineGeom &g, SweepScal s, unsigned *queue, hipStream_t st, const Fuse &fz)
 {
     unsigned ggrid = (unsigned)P.ntiles_g;
     if (queue != nullptr) {
         (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
-        if (P.Mf == 32) launch_condense_fast<32, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st);
-        else if (P.Mf == 16) launch_condense_fast<16, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st);
-        else launch_condense_fast<8, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st);
+        // (the 32-row wide tiling is not built with the fused loader: the host plans fused passes without it)
+        if (P.Mf == 32) launch_condense_fast<32, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st, fz);
+        else if (P.Mf == 16) launch_condense_fast<16, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st, fz);
+        else launch_condense_fast<8, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st, fz);
         ggrid = P.ntiles_g < 1024 ? (unsigned)P.ntiles_g : 1024u;
     }
-    hipLaunchKernelGGL((k_condense_strided<M, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(P.lines_g * P.Lpg), P.lds_g, st, in,
-                       flags, coeff, dmask, dval, qf, cond, nlines, g, P.Lpg, P.lines_g, P.tiles_inner_g, P.ntiles_g, s,
-                       queue, P.ratio, P.tiles_inner_f);
+    hipLaunchKernelGGL((k_condense_strided<M, HAS_DIR, HAS_Q, FUSE>), dim3(ggrid), dim3(P.lines_g * P.Lpg), P.lds_g, st,
+                       in, flags, coeff, dmask, dval, qf, cond, nlines, g, P.Lpg, P.lines_g, P.tiles_inner_g, P.ntiles_g,
+                       s, queue, P.ratio, P.tiles_inner_f, fz);
 }
 
 template <bool HAS_DIR, bool HAS_Q>
 static int sweep_dispatch(int axis, const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
                           const double *dval, const double *qf, const Lay &L, SweepScal s, double *out,
-                          const double *xlo, const double *xhi, void *work, size_t work_bytes, hipStream_t st)
+                          const double *xlo, const double *xhi, void *work, size_t work_bytes, hipStream_t st,
+                          const Fuse *fzp = nullptr)
 {
     long inner_stride;
     const LineGeom g = line_geom(axis, L, &inner_stride);
     const int n = g.n;
+    if (fzp != nullptr && (axis != 0 || n > kMaxFastLine))
+        return set_err(ADI_ERR_UNSUPPORTED, "fused explicit + sweep: axis 0 with at most %d planes only", kMaxFastLine);
     if (n > kMaxFastLine || (axis == 2 && (xlo || xhi))) {
         const size_t need = (size_t)2 * L.nx * L.sx * sizeof(double);
         if (work == nullptr || work_bytes < need)
@@ -1683,24 +1897,45 @@ static int sweep_dispatch(int axis, const double *in, const uint8_t *flags, cons
     } else {
         static int wide = -1;
         if (wide < 0) wide = getenv("ADI_STRIDED_WIDE") ? atoi(getenv("ADI_STRIDED_WIDE")) : 0;
-        StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr, wide != 0);
+        StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr, wide != 0 && fzp == nullptr);
         unsigned *queue = nullptr;
         if (P.Mf && use_fast(s, work, work_bytes, P.ntiles_f)) queue = (unsigned *)work;
         else if (P.Mf) P = strided_plan(g, false, false);
+        if (fzp != nullptr) {
+            Fuse fz = *fzp;
+            if (queue != nullptr && !fuse_fast_ok(P)) { queue = nullptr; P = strided_plan(g, false, false); }
+            fuse_tile_order(fz, P, L);
+            switch (P.Mg) {
+                case 2: launch_strided<2, HAS_DIR, HAS_Q, true>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz); break;
+                case 4: launch_strided<4, HAS_DIR, HAS_Q, true>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz); break;
+                case 8: launch_strided<8, HAS_DIR, HAS_Q, true>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz); break;
+                default: launch_strided<16, HAS_DIR, HAS_Q, true>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz); break;
+            }
+            return ADI_OK;
+        }
+        const Fuse fz = Fuse();
         switch (P.Mg) {
-            case 2: launch_strided<2, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st); break;
-            case 4: launch_strided<4, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st); break;
-            case 8: launch_strided<8, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st); break;
-            default: launch_strided<16, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st); break;
+            case 2: launch_strided<2, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz); break;
+            case 4: launch_strided<4, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz); break;
+            case 8: launch_strided<8, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz); break;
+            default: launch_strided<16, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz); break;
         }
     }
     return ADI_OK;
 }
 
+// whole-segment condition of the tiled pass-A kernels (also what adi_explicit_fused_supported reports)
+static bool condense_is_tiled(int axis, int n)
+{
+    if (axis == 2 || n > kMaxFastLine) return false;
+    const int mg = strided_rows_per_thread(n);
+    return (n % mg == 0) && (n / mg <= 64);
+}
+
 template <bool HAS_DIR, bool HAS_Q>
 static int condense_dispatch(int axis, const double *in, const uint8_t *flags, const double *coeff,
                              const uint8_t *dmask, const double *dval, const double *qf, const Lay &L, SweepScal s,
-                             double *cond, void *work, size_t work_bytes, hipStream_t st)
+                             double *cond, void *work, size_t work_bytes, hipStream_t st, const Fuse *fzp = nullptr)
 {
     long inner_stride;
     const LineGeom g = line_geom(axis, L, &inner_stride);
@@ -1709,18 +1944,33 @@ static int condense_dispatch(int axis, const double *in, const uint8_t *flags, c
     bool tiled = false;
     StridedPlan P;
     if (axis != 2 && n <= kMaxFastLine) {
-        P = strided_plan(g, s.sparse != 0 && work != nullptr, true);
+        P = strided_plan(g, s.sparse != 0 && work != nullptr, fzp == nullptr);
         tiled = (n % P.Mg == 0) && (n / P.Mg <= 64);     // the tiled kernels need whole segments
     }
+    if (fzp != nullptr && (axis != 0 || !tiled))
+        return set_err(ADI_ERR_UNSUPPORTED, "fused explicit + condensation: axis 0, whole segments only (n = %d)", n);
     if (tiled) {
         unsigned *queue = nullptr;
         if (P.Mf && use_fast(s, work, work_bytes, P.ntiles_f)) queue = (unsigned *)work;
         else if (P.Mf) P = strided_plan(g, false, false);
+        if (fzp != nullptr) {
+            Fuse fz = *fzp;
+            if (queue != nullptr && !fuse_fast_ok(P)) { queue = nullptr; P = strided_plan(g, false, false); }
+            fuse_tile_order(fz, P, L);
+            switch (P.Mg) {
+                case 2: launch_condense<2, HAS_DIR, HAS_Q, true>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st, fz); break;
+                case 4: launch_condense<4, HAS_DIR, HAS_Q, true>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st, fz); break;
+                case 8: launch_condense<8, HAS_DIR, HAS_Q, true>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st, fz); break;
+                default: launch_condense<16, HAS_DIR, HAS_Q, true>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st, fz); break;
+            }
+            return ADI_OK;
+        }
+        const Fuse fz = Fuse();
         switch (P.Mg) {
-            case 2: launch_condense<2, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st); break;
-            case 4: launch_condense<4, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st); break;
-            case 8: launch_condense<8, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st); break;
-            default: launch_condense<16, HAS_DIR, HAS_Q>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st); break;
+            case 2: launch_condense<2, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st, fz); break;
+            case 4: launch_condense<4, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st, fz); break;
+            case 8: launch_condense<8, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st, fz); break;
+            default: launch_condense<16, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st, fz); break;
         }
     } else {
         hipLaunchKernelGGL((k_condense_generic<HAS_DIR, HAS_Q>), dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0,
@@ -1903,10 +2153,11 @@ static int variant_flags(int variant, bool *has_dir, bool *has_q)
     return ADI_OK;
 }
 
-int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
-              const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
-              long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
-              const double *d_xlo, const double *d_xhi, void *d_work, size_t work_bytes, void *stream)
+static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
+                       const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
+                       long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
+                       const double *d_xlo, const double *d_xhi, void *d_work, size_t work_bytes, void *stream,
+                       const Fuse *fz)
 {
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep: bad axis %d", axis);
     bool has_dir, has_q;
@@ -1924,19 +2175,63 @@ int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags,
     s.sparse = sparse ? 1 : 0;
     hipStream_t st = as_stream(stream);
     int rc;
-    if (has_dir && has_q) rc = sweep_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st);
-    else if (has_q) rc = sweep_dispatch<false, true>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, d_qflux, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st);
-    else if (has_dir) rc = sweep_dispatch<true, false>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, nullptr, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st);
-    else rc = sweep_dispatch<false, false>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, nullptr, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st);
+    if (has_dir && has_q) rc = sweep_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st, fz);
+    else if (has_q) rc = sweep_dispatch<false, true>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, d_qflux, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st, fz);
+    else if (has_dir) rc = sweep_dispatch<true, false>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, nullptr, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st, fz);
+    else rc = sweep_dispatch<false, false>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, nullptr, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st, fz);
     if (rc != ADI_OK) return rc;
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }
 
-int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
-                       const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny,
-                       int nz, long plane_stride, int sparse, double theta, double gam, double dt, double Tinf,
-                       double *d_cond, void *d_work, size_t work_bytes, void *stream)
+int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
+              const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
+              long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
+              const double *d_xlo, const double *d_xhi, void *d_work, size_t work_bytes, void *stream)
+{
+    return sweep_entry(axis, variant, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
+                       sparse, theta, gam, dt, Tinf, d_out, d_xlo, d_xhi, d_work, work_bytes, stream, nullptr);
+}
+
+static Fuse make_fuse(int nz, double dx, double dt, double kappa, double theta, long valid_lo, long valid_hi)
+{
+    Fuse fz;
+    fz.invdx2 = 1.0 / (dx * dx);                 // the same two expressions as adi_explicit_rhs_planes
+    fz.f = dt * kappa * (1.0 - theta);
+    fz.sy = nz;
+    fz.vlo = valid_lo;
+    fz.vhi = valid_hi;
+    fz.kt = 0; fz.ny = 0; fz.kg = 0;
+    return fz;
+}
+
+int adi_explicit_fused_supported(int nx, int ny, int nz, long plane_stride, int pass)
+{
+    (void)ny; (void)nz; (void)plane_stride;
+    static int off = -1;
+    if (off < 0) off = getenv("ADI_NO_FUSE") ? 1 : 0;
+    if (off || nx <= 0) return 0;
+    return pass == 0 ? (nx <= kMaxFastLine) : (condense_is_tiled(0, nx) ? 1 : 0);
+}
+
+int adi_explicit_sweep0(int variant, const double *d_T, long valid_lo, long valid_hi, const uint8_t *d_flags,
+                        const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
+                        const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse, double dx,
+                        double dt, double kappa, double theta, double Tinf, double *d_out, const double *d_xlo,
+                        const double *d_xhi, void *d_work, size_t work_bytes, void *stream)
+{
+    ADI_REQUIRE(valid_lo <= 0 && valid_hi >= (long)(nx - 1) * (plane_stride ? plane_stride : (long)ny * nz) + (long)ny * nz,
+                "adi_explicit_sweep0: the readable range [%ld, %ld) does not cover the box", valid_lo, valid_hi);
+    const Fuse fz = make_fuse(nz, dx, dt, kappa, theta, valid_lo, valid_hi);
+    const double gam = kappa * dt / (dx * dx);   // adi3d_numba_coeff.py:292
+    return sweep_entry(0, variant, d_T, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
+                       sparse, theta, gam, dt, Tinf, d_out, d_xlo, d_xhi, d_work, work_bytes, stream, &fz);
+}
+
+static int condense_entry(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
+                          const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny,
+                          int nz, long plane_stride, int sparse, double theta, double gam, double dt, double Tinf,
+                          double *d_cond, void *d_work, size_t work_bytes, void *stream, const Fuse *fz)
 {
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep_condense: bad axis %d", axis);
     bool has_dir, has_q;
@@ -1952,12 +2247,37 @@ int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t 
     s.Tinf = Tinf;
     s.sparse = sparse ? 1 : 0;
     hipStream_t st = as_stream(stream);
-    if (has_dir && has_q) condense_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, L, s, d_cond, d_work, work_bytes, st);
-    else if (has_q) condense_dispatch<false, true>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, d_qflux, L, s, d_cond, d_work, work_bytes, st);
-    else if (has_dir) condense_dispatch<true, false>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, nullptr, L, s, d_cond, d_work, work_bytes, st);
-    else condense_dispatch<false, false>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, nullptr, L, s, d_cond, d_work, work_bytes, st);
+    int rc;
+    if (has_dir && has_q) rc = condense_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, L, s, d_cond, d_work, work_bytes, st, fz);
+    else if (has_q) rc = condense_dispatch<false, true>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, d_qflux, L, s, d_cond, d_work, work_bytes, st, fz);
+    else if (has_dir) rc = condense_dispatch<true, false>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, nullptr, L, s, d_cond, d_work, work_bytes, st, fz);
+    else rc = condense_dispatch<false, false>(axis, d_in, d_flags, d_coeff, nullptr, nullptr, nullptr, L, s, d_cond, d_work, work_bytes, st, fz);
+    if (rc != ADI_OK) return rc;
     ADI_CHECK_LAUNCH();
     return ADI_OK;
+}
+
+int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
+                       const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny,
+                       int nz, long plane_stride, int sparse, double theta, double gam, double dt, double Tinf,
+                       double *d_cond, void *d_work, size_t work_bytes, void *stream)
+{
+    return condense_entry(axis, variant, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
+                          sparse, theta, gam, dt, Tinf, d_cond, d_work, work_bytes, stream, nullptr);
+}
+
+int adi_explicit_condense0(int variant, const double *d_T, long valid_lo, long valid_hi, const uint8_t *d_flags,
+                           const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
+                           const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse, double dx,
+                           double dt, double kappa, double theta, double Tinf, double *d_cond, void *d_work,
+                           size_t work_bytes, void *stream)
+{
+    ADI_REQUIRE(valid_lo <= 0 && valid_hi >= (long)(nx - 1) * (plane_stride ? plane_stride : (long)ny * nz) + (long)ny * nz,
+                "adi_explicit_condense0: the readable range [%ld, %ld) does not cover the box", valid_lo, valid_hi);
+    const Fuse fz = make_fuse(nz, dx, dt, kappa, theta, valid_lo, valid_hi);
+    const double gam = kappa * dt / (dx * dx);
+    return condense_entry(0, variant, d_T, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
+                          sparse, theta, gam, dt, Tinf, d_cond, d_work, work_bytes, stream, &fz);
 }
 
 int adi_interface_solve(const double *d_cond_all, int nranks, int rank, long nlines, double *d_xlo, double *d_xhi,
@@ -1995,9 +2315,18 @@ int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_t
     const double kappa = k / (rho * cp);
     const double gam = kappa * dt / (dx * dx);
     const double *q0 = d_qflux ? d_qflux[0] : nullptr, *q1 = d_qflux ? d_qflux[1] : nullptr, *q2 = d_qflux ? d_qflux[2] : nullptr;
-    int rc = adi_explicit_rhs(d_T_in, d_flags, nx, ny, nz, plane_stride, dx, dt, kappa, theta, d_tmp_a, stream);
-    if (rc) return rc;
-    rc = adi_sweep(0, variant, d_tmp_a, d_flags, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_b, nullptr, nullptr, d_work, work_bytes, stream);
+    int rc;
+    if (adi_explicit_fused_supported(nx, ny, nz, plane_stride, 0)) {
+        // stages 1+2 in one pass: R0 is evaluated inside the loads of the axis-0 sweep
+        const long sxe = plane_stride ? plane_stride : (long)ny * nz;
+        rc = adi_explicit_sweep0(variant, d_T_in, 0, (long)(nx - 1) * sxe + (long)ny * nz, d_flags, d_coeff[0], d_dir_mask,
+                                 d_dir_val, q0, nx, ny, nz, plane_stride, sparse, dx, dt, kappa, theta, Tinf, d_tmp_b,
+                                 nullptr, nullptr, d_work, work_bytes, stream);
+    } else {
+        rc = adi_explicit_rhs(d_T_in, d_flags, nx, ny, nz, plane_stride, dx, dt, kappa, theta, d_tmp_a, stream);
+        if (rc) return rc;
+        rc = adi_sweep(0, variant, d_tmp_a, d_flags, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_b, nullptr, nullptr, d_work, work_bytes, stream);
+    }
     if (rc) return rc;
     rc = adi_sweep(1, variant, d_tmp_b, d_flags, d_coeff[1], d_dir_mask, d_dir_val, q1, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_a, nullptr, nullptr, d_work, work_bytes, stream);
     if (rc) return rc;

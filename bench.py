@@ -103,6 +103,7 @@ def main():
         packs = adi.precompute_coeff_packs_unified(grid, mat, robin_h=500.0)
         T = adi.DeviceField(T0)
         stepper = adi.StagedStepper(grid, mat, prm, packs, Tinf)
+        stage_names = stepper.stage_names      # explicit stage folded into the axis-0 sweep where supported
         variant = packs[0].variant
     else:
         from adi_thermal_fields_amd import dist_slab

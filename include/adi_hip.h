@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 6
+#define ADI_ABI_VERSION 7
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -138,6 +138,30 @@ int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t 
                        const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse,
                        double theta, double gam, double dt, double Tinf, double *d_cond,
                        void *d_work, size_t work_bytes, void *stream);
+/*
+ * Explicit stage folded into the axis-0 sweep (ABI v7): lap1D_x/y/z + R0 (adi3d_numba_coeff.py:240-288, :292-298)
+ * are evaluated inside the loads of sweep_axis0 (:133-166, :299), so R0 never travels through HBM -- the first two
+ * stages of adi_step_numba_coeff cost one read of T and one write of U.  Same arithmetic in the same order as
+ * adi_explicit_rhs followed by adi_sweep(axis 0): the result is bit-identical to running the two stages.
+ * d_T: the state (the `Tn` of the step), box (nx, ny, nz) with plane_stride; neighbours outside the box are read
+ * where the flags byte says they exist (halo planes of a slab, rows next to a sub-box of lines), so the caller states
+ * which element offsets relative to d_T may be read: [valid_lo, valid_hi) must cover the box and lie inside the
+ * allocation (whole buffer: valid_lo = -(offset of d_T in it), valid_hi = its length - that offset).
+ * adi_explicit_fused_supported(pass): 1 when pass 0 (sweep) / pass 1 (condensation) can run fused on this box
+ * (nx <= 1024 planes; pass 1: whole register segments); otherwise run adi_explicit_rhs + adi_sweep.
+ */
+int adi_explicit_fused_supported(int nx, int ny, int nz, long plane_stride, int pass);
+int adi_explicit_sweep0(int variant, const double *d_T, long valid_lo, long valid_hi, const uint8_t *d_flags,
+                        const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
+                        const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse,
+                        double dx, double dt, double kappa, double theta, double Tinf,
+                        double *d_out, const double *d_xlo, const double *d_xhi,
+                        void *d_work, size_t work_bytes, void *stream);
+int adi_explicit_condense0(int variant, const double *d_T, long valid_lo, long valid_hi, const uint8_t *d_flags,
+                           const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
+                           const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse,
+                           double dx, double dt, double kappa, double theta, double Tinf,
+                           double *d_cond, void *d_work, size_t work_bytes, void *stream);
 /* d_cond_all: [nranks][6][nlines], the all-gathered pass-A output ordered by slab.  Solves the reduced
  * interface system of every line and writes this rank's boundary values for pass B (adi_sweep). */
 int adi_interface_solve(const double *d_cond_all, int nranks, int rank, long nlines,

@@ -232,3 +232,44 @@ def test_very_long_lines(hip, shape):
     got = run_cart_case(hip, c2)['T_final']
     want = run_cart_case(orc, c2)['T_final']
     assert rel_linf(got, want) <= TOL, rel_linf(got, want)
+
+
+@pytest.mark.parametrize('shape,fill', [((512, 6, 40), 1.0), ((512, 5, 24), 0.97), ((64, 33, 48), 0.9), ((257, 4, 18), 1.0),
+                                        ((16, 16, 16), 0.8), ((128, 9, 130), 1.0), ((3, 7, 5), 0.7), ((1, 4, 6), 1.0)])
+@pytest.mark.parametrize('bc', ['lean', 'general'])
+def test_fused_explicit_sweep0_is_bit_identical(hip, shape, fill, bc):
+    """adi_explicit_sweep0 (explicit stage evaluated inside the loads of the axis-0 sweep, FAST and queued GENERAL
+    tiles, sparse and dense packs) against adi_explicit_rhs + adi_sweep(axis 0): the same arithmetic in the same
+    order, so the two must agree bit for bit; and against the oracle's U at the parity bar."""
+    from adi_thermal_fields_amd import _lib
+    rng = np.random.default_rng(sum(shape) + len(bc))
+    mask = rng.random(shape) < fill
+    mask[shape[0] // 2:, :, :] |= rng.random((shape[0] - shape[0] // 2,) + shape[1:]) < 0.995   # mostly solid half
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    grid = hip.Grid3D(*shape, dx, mask)
+    assert hip.fused_supported(grid)
+    mat = hip.Material(7800.0, 490.0, 54.0)
+    prm = hip.Params(150.0 * dx * dx / alpha, 0.5)
+    kw = dict(robin_h=350.0)
+    if bc == 'general':
+        dm = np.zeros(shape, bool); dm[:, 0, :] = mask[:, 0, :]
+        kw.update(dir_mask=dm, dir_value=77.0, neumann={'x+': 2e5, 'z-': rng.uniform(0, 1e5, shape)})
+    packs = hip.precompute_coeff_packs_unified(grid, mat, **kw)
+    T0 = rng.uniform(20.0, 1500.0, shape)
+    R0 = hip.adi_explicit_rhs(T0, grid, mat, prm)
+    for variant, dense in ((None, False), (_lib.SWEEP_GENERAL, True)):
+        two = hip.adi_sweep_axis(0, R0, grid, mat, prm, packs[0], Tinf=25.0, variant=variant, dense=dense)
+        one = hip.adi_explicit_sweep_axis0(T0, grid, mat, prm, packs[0], Tinf=25.0, variant=variant, dense=dense)
+        assert np.array_equal(one, two), (variant, dense, float(np.abs(one - two).max()))
+    # a view into a larger buffer (halo planes around it, like a slab): neighbours outside the box are read
+    # wherever the flags say so -- here they never do, and the result must not change
+    import torch
+    L = grid.layout
+    big = torch.full(((shape[0] + 2) * L.sx,), float('nan'), dtype=torch.float64, device='cuda')
+    view = big.as_strided(L.shape, L.strides, L.sx)
+    view.copy_(torch.from_numpy(T0))
+    out = L.empty()
+    hip._explicit_sweep0_into(view, out, grid, mat, prm, packs[0], 25.0)
+    assert np.array_equal(out.cpu().numpy(), one if variant is None else
+                          hip.adi_explicit_sweep_axis0(T0, grid, mat, prm, packs[0], Tinf=25.0))
