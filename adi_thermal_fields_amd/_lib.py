@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libadi_hip.so')
+LIB_PATH = os.environ.get('ADI_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libadi_hip.so')   # env: A/B builds of the kernels
 
 ADI_OK, ADI_ERR_ARG, ADI_ERR_HIP, ADI_ERR_UNSUPPORTED, ADI_ERR_STATE = 0, 1, 2, 3, 4
 FACE_NONE, FACE_SCALAR, FACE_FIELD = 0, 1, 2

@@ -26,6 +26,13 @@
 
 namespace adi {
 
+#ifndef ADI_FUSE_D
+#define ADI_FUSE_D 8     // rows of j-neighbour loads in flight per thread in the fused FAST kernels (2: 0.77 ms, 4: 0.70, 8: 0.68 at 512^3)
+#endif
+#ifndef ADI_FUSE_OCC
+#define ADI_FUSE_OCC 4   // waves per SIMD the fused FAST kernels are compiled for (4: two 512-thread workgroups per CU)
+#endif
+
 struct SweepScal {
     double tg;    // theta * gamma
     double dt;
@@ -63,6 +70,8 @@ struct Fuse {
     long sy;
     long vlo, vhi;
     int kt, ny, kg;     // FAST kernel tile order: kt tiles per j-row, groups of kg k-tiles walked j-fastest (kg = 0: off)
+    long wlo;           // FAST kernel: the buffer descriptor of the state covers [wlo, wlo + wbytes/8) relative to `in`
+    unsigned wbytes;    // (0: the window would not fit 32-bit offsets, GENERAL kernel only)
 };
 
 // FUSE tile order: the j-neighbour rows a tile re-reads belong to the tiles of the adjacent j-rows; walking groups of kg
@@ -700,9 +709,25 @@ __device__ __forceinline__ double row_bcast(double v, int r)
     }
 }
 
+// Buffer addressing (raw_buffer_load/store: 128-bit descriptor + per-thread 32-bit byte offset + scalar byte offset):
+// a strided tile touches M rows x several arrays, and with flat global loads every one of them costs 64-bit address
+// arithmetic in the VALU (measured: half of the fused kernel's VALU instructions); here the row offsets live in
+// scalar registers and one per-thread offset serves every load.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x)
+{
+    u32x2 v;
+    v.x = (unsigned)__double2loint(x); v.y = (unsigned)__double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+
 template <int M, bool HAS_DIR>
-__device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict__ in_t,
-                                                        const uint8_t *__restrict__ flags_t,
+__device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict__ in, const uint8_t *__restrict__ flags_t,
                                                         const uint8_t *__restrict__ dmask_t, const LineGeom &g,
                                                         unsigned voff, int r0, int kk, long tbase, const Fuse &fz,
                                                         double (&d)[M], unsigned &f0, unsigned &fS, bool &dirS)
@@ -710,25 +735,31 @@ __device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict
 #pragma clang fp contract(off)
     constexpr int LINES = 16;
     const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
+    // the state through a descriptor over the window [wlo, wlo + wbytes/8) of `in` (host: covers every neighbour of
+    // the box that exists in memory, < 4 GiB); flags through one based at the tile
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void *)(in + fz.wlo), 0, (int)fz.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void *)flags_t, 0, 0x7fffffff, 0x00020000);
+    const unsigned vb = voff * 8u;                                   // this thread's row 0, bytes from the tile base
+    const unsigned R0 = (unsigned)((tbase - fz.wlo) * 8);            // tile base, bytes from the window start (scalar)
+    const unsigned st8 = (unsigned)(g.stride * 8), sy8 = (unsigned)(fz.sy * 8);
+    // Every load below is unconditional.  Rows whose neighbour always lies inside the window take the scalar row offset;
+    // the few that can fall outside it (first row: i-1, j-1, k0-1; last row: i+1, j+1, k0+16) carry the whole offset in
+    // the per-thread register, where the descriptor's range check turns an address before or after the window into a
+    // load of 0 -- such a neighbour does not exist and the flags byte says so.
     unsigned fb[M];
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-        fb[r] = (flags_t + (size_t)r * g.stride)[voff];
-        d[r] = (in_t + (size_t)r * g.stride)[voff];
+        fb[r] = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * (unsigned)g.stride, 0);
+        d[r] = buf_load_f64(rT, vb, R0 + (unsigned)r * st8);
     }
-    const long p0 = tbase + (long)voff;                     // offset of this thread's row 0 relative to `in`
-    const bool first = r0 == 0, last = r0 + M >= g.n;
-    const long pl = p0 + (long)(M - 1) * g.stride;
-    double tim = 0.0, tip = 0.0;
-    if (!first || p0 - g.stride >= fz.vlo) tim = (in_t - (size_t)g.stride)[voff];
-    if (!last || pl + g.stride < fz.vhi) tip = (in_t + (size_t)M * g.stride)[voff];
-    double eL = 0.0, eR = 0.0;
-    if (kk < M) {
-        const long pe = tbase + (long)(r0 + kk) * g.stride;
-        const double *rowe = in_t + (size_t)(r0 + kk) * g.stride;
-        if (pe - 1 >= fz.vlo) eL = rowe[-1];
-        if (pe + LINES < fz.vhi) eR = rowe[LINES];
-    }
+    const unsigned vw = vb + R0;                                     // this thread's row 0, bytes from the window start
+    const unsigned vl = vw + (unsigned)(M - 1) * st8;                // its last row
+    const double tim = buf_load_f64(rT, vw - st8, 0u);
+    const double tip = buf_load_f64(rT, vl + st8, 0u);
+    // k-neighbours outside the tile, loaded transposed: lane kk fetches the pair of row kk (columns k0-1, k0+16)
+    const unsigned ve = R0 + (unsigned)(r0 + (int)(threadIdx.x & 15u)) * st8;
+    const double eL = buf_load_f64(rT, ve - 8u, 0u);
+    const double eR = buf_load_f64(rT, ve + LINES * 8u, 0u);
     bool lane_fast = true, full = true;
 #pragma unroll
     for (int r = 0; r < M; ++r) {
@@ -738,40 +769,44 @@ __device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict
     }
     f0 = fb[0]; fS = fb[M - 1];
     const bool wave_full = __all(full);                     // every cell of this wave has its six neighbours
-    const double two_inv = fz.invdx2;
+    // j-neighbour rows: a software pipeline D rows deep (they are L2 hits -- the tiles of the adjacent j-rows run next
+    // door on the same XCD -- so a short pipeline covers their latency; a register pair per row in flight).  The
+    // sched_barriers pin the order: without them the scheduler hoists every load to the top and spills.
+    constexpr int D = (M >= 8) ? ADI_FUSE_D : M;
+    auto load_jm = [&](int r) -> double {
+        return (r == 0) ? buf_load_f64(rT, vw - sy8, 0u) : buf_load_f64(rT, vb, R0 + (unsigned)r * st8 - sy8);
+    };
+    auto load_jp = [&](int r) -> double {
+        return (r == M - 1) ? buf_load_f64(rT, vl + sy8, 0u) : buf_load_f64(rT, vb, R0 + (unsigned)r * st8 + sy8);
+    };
+    double hm[D], hp[D];
+#pragma unroll
+    for (int q = 0; q < D; ++q) { hm[q] = load_jm(q); hp[q] = load_jp(q); }
     double prev = tim;
-    constexpr int H = (M >= 8) ? M / 2 : M;                 // j-halo rows in flight at once (register budget)
 #pragma unroll
-    for (int h = 0; h < M / H; ++h) {
-        double jm[H], jp[H];
-#pragma unroll
-        for (int q = 0; q < H; ++q) {
-            const int r = h * H + q;
-            const double *row = in_t + (size_t)r * g.stride;
-            jm[q] = 0.0; jp[q] = 0.0;
-            if (r > 0 || !first || p0 - fz.sy >= fz.vlo) jm[q] = (row - fz.sy)[voff];
-            if (r < M - 1 || !last || pl + fz.sy < fz.vhi) jp[q] = (row + fz.sy)[voff];
+    for (int r = 0; r < M; ++r) {
+        __builtin_amdgcn_sched_barrier(0);
+        const double cur = d[r];
+        const double nxt = (r < M - 1) ? d[r + 1] : tip;     // still the state: rows are overwritten in order
+        const double jm = hm[r % D], jp = hp[r % D];
+        const double km = dpp_mov<0x111>(row_bcast(eL, r), cur), kp = dpp_mov<0x101>(row_bcast(eR, r), cur);
+        if (wave_full) {
+            // lap_axis with both neighbours present, same operation order: ((0 + lo) + hi - 2*t) * invdx2
+            const double c2 = 2.0 * cur;
+            const double L0 = (((0.0 + prev) + nxt) - c2) * fz.invdx2;
+            const double L1 = (((0.0 + jm) + jp) - c2) * fz.invdx2;
+            const double L2 = (((0.0 + km) + kp) - c2) * fz.invdx2;
+            d[r] = cur + fz.f * ((L0 + L1) + L2);
+        } else {
+            d[r] = explicit_cell(fb[r], cur, prev, nxt, jm, jp, km, kp, fz);
         }
-#pragma unroll
-        for (int q = 0; q < H; ++q) {
-            const int r = h * H + q;
-            const double cur = d[r];
-            const double nxt = (r < M - 1) ? d[r + 1] : tip;     // still the state: rows are overwritten in order
-            const double el = row_bcast(eL, r), er = row_bcast(eR, r);
-            const double km = dpp_mov<0x111>(el, cur), kp = dpp_mov<0x101>(er, cur);
-            if (wave_full) {
-                // lap_axis with both neighbours present, same operation order: ((0 + lo) + hi - 2*t) * invdx2
-                const double c2 = 2.0 * cur;
-                const double L0 = (((0.0 + prev) + nxt) - c2) * two_inv;
-                const double L1 = (((0.0 + jm[q]) + jp[q]) - c2) * two_inv;
-                const double L2 = (((0.0 + km) + kp) - c2) * two_inv;
-                d[r] = cur + fz.f * ((L0 + L1) + L2);
-            } else {
-                d[r] = explicit_cell(fb[r], cur, prev, nxt, jm[q], jp[q], km, kp, fz);
-            }
-            prev = cur;
+        prev = cur;
+        if (r + D < M) {
+            __builtin_amdgcn_sched_barrier(0);
+            hm[r % D] = load_jm(r + D); hp[r % D] = load_jp(r + D);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
     dirS = false;
     if (HAS_DIR) {
 #pragma unroll
@@ -805,7 +840,7 @@ __device__ __forceinline__ void fast_segment_ends(const double *__restrict__ coe
 
 // FAST kernel (sparse packs): tiles whose every segment is uniform-interior (see k_sweep_contig_fast)
 template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
-__global__ __launch_bounds__(512, FUSE ? 4 : 1) void k_sweep_strided_fast(
+__global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_fast(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ out, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
@@ -838,8 +873,8 @@ __global__ __launch_bounds__(512, FUSE ? 4 : 1) void k_sweep_strided_fast(
             if (tid == 0) enqueue_unit(queue, (unsigned)tile);
             return;
         }
-        lane_fast = fast_segment_load_fused<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff,
-                                                        r0, kk, tbase, fz, d, f0, fS, dirS);
+        lane_fast = fast_segment_load_fused<M, HAS_DIR>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0, kk,
+                                                        tbase, fz, d, f0, fS, dirS);
     } else {
         lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
                                                   active, d, f0, fS, dirS);
@@ -865,8 +900,14 @@ __global__ __launch_bounds__(512, FUSE ? 4 : 1) void k_sweep_strided_fast(
     tile_separators(sm, tid, kk, sg, Lp, LINES, aS, bS, cS, d[M - 1], k, xL, xS);
     back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
     double *out_t = out + tbase;
+    if constexpr (FUSE) {
+        const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)out_t, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int r = 0; r < M; ++r) (out_t + (size_t)r * g.stride)[voff] = d[r];
+        for (int r = 0; r < M; ++r) buf_store_f64(rO, voff * 8u, (unsigned)r * (unsigned)(g.stride * 8), d[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < M; ++r) (out_t + (size_t)r * g.stride)[voff] = d[r];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -960,7 +1001,7 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_condense_strided(
 // FAST pass A: uniform-interior segments (see k_sweep_strided_fast); the block of a thread = its M-1 uniform
 // interior rows merged with its general separator row.
 template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
-__global__ __launch_bounds__(512, FUSE ? 4 : 1) void k_condense_strided_fast(
+__global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_condense_strided_fast(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ cond, long nlines, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
@@ -991,8 +1032,8 @@ __global__ __launch_bounds__(512, FUSE ? 4 : 1) void k_condense_strided_fast(
             if (tid == 0) enqueue_unit(queue, (unsigned)tile);
             return;
         }
-        lane_fast = fast_segment_load_fused<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff,
-                                                        r0, kk, tbase, fz, d, f0, fS, dirS);
+        lane_fast = fast_segment_load_fused<M, HAS_DIR>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0, kk,
+                                                        tbase, fz, d, f0, fS, dirS);
     } else {
         lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
                                                   active, d, f0, fS, dirS);
@@ -1792,12 +1833,15 @@ static StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok)
 }
 
 // the fused FAST kernels shuffle k-neighbours inside 16-lane DPP rows: 16 lines per tile, at most 16 rows per thread
-static bool fuse_fast_ok(const StridedPlan &P) { return P.Mf != 0 && P.lines_f == 16 && P.Mf <= 16; }
+static bool fuse_fast_ok(const StridedPlan &P, const Lay &L, const Fuse &fz)
+{
+    return P.Mf != 0 && P.lines_f == 16 && P.Mf <= 16 && L.nz % 16 == 0 && fz.wbytes != 0;
+}
 
 static void fuse_tile_order(Fuse &fz, const StridedPlan &P, const Lay &L)
 {
     static int kg = -1;
-    if (kg < 0) { const char *e = getenv("ADI_FUSE_KG"); kg = e ? atoi(e) : 4; if (kg < 0 || (kg & (kg - 1))) kg = 4; }
+    if (kg < 0) { const char *e = getenv("ADI_FUSE_KG"); kg = e ? atoi(e) : 8; if (kg < 0 || (kg & (kg - 1))) kg = 8; }
     fz.kt = 0; fz.ny = L.ny; fz.kg = 0;
     if (P.Mf != 0 && kg > 0 && L.nz % P.lines_f == 0) {
         const int kt = L.nz / P.lines_f;
@@ -1903,7 +1947,7 @@ static int sweep_dispatch(int axis, const double *in, const uint8_t *flags, cons
         else if (P.Mf) P = strided_plan(g, false, false);
         if (fzp != nullptr) {
             Fuse fz = *fzp;
-            if (queue != nullptr && !fuse_fast_ok(P)) { queue = nullptr; P = strided_plan(g, false, false); }
+            if (queue != nullptr && !fuse_fast_ok(P, L, fz)) { queue = nullptr; P = strided_plan(g, false, false); }
             fuse_tile_order(fz, P, L);
             switch (P.Mg) {
                 case 2: launch_strided<2, HAS_DIR, HAS_Q, true>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz); break;
@@ -1955,7 +1999,7 @@ static int condense_dispatch(int axis, const double *in, const uint8_t *flags, c
         else if (P.Mf) P = strided_plan(g, false, false);
         if (fzp != nullptr) {
             Fuse fz = *fzp;
-            if (queue != nullptr && !fuse_fast_ok(P)) { queue = nullptr; P = strided_plan(g, false, false); }
+            if (queue != nullptr && !fuse_fast_ok(P, L, fz)) { queue = nullptr; P = strided_plan(g, false, false); }
             fuse_tile_order(fz, P, L);
             switch (P.Mg) {
                 case 2: launch_condense<2, HAS_DIR, HAS_Q, true>(P, in, flags, coeff, dmask, dval, qf, cond, nlines, g, s, queue, st, fz); break;
@@ -2193,7 +2237,8 @@ int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags,
                        sparse, theta, gam, dt, Tinf, d_out, d_xlo, d_xhi, d_work, work_bytes, stream, nullptr);
 }
 
-static Fuse make_fuse(int nz, double dx, double dt, double kappa, double theta, long valid_lo, long valid_hi)
+static Fuse make_fuse(int nx, int ny, int nz, long plane_stride, double dx, double dt, double kappa, double theta,
+                      long valid_lo, long valid_hi)
 {
     Fuse fz;
     fz.invdx2 = 1.0 / (dx * dx);                 // the same two expressions as adi_explicit_rhs_planes
@@ -2202,6 +2247,13 @@ static Fuse make_fuse(int nz, double dx, double dt, double kappa, double theta, 
     fz.vlo = valid_lo;
     fz.vhi = valid_hi;
     fz.kt = 0; fz.ny = 0; fz.kg = 0;
+    // window of the state the FAST kernel's buffer descriptor covers: the box, one plane + one row + one tile around it
+    const long sx = plane_stride ? plane_stride : (long)ny * nz;
+    const long box_end = (long)(nx - 1) * sx + (long)ny * nz;
+    const long wlo = valid_lo > -(sx + nz + 16) ? valid_lo : -(sx + nz + 16);
+    const long whi = valid_hi < box_end + sx + nz + 32 ? valid_hi : box_end + sx + nz + 32;
+    fz.wlo = wlo;
+    fz.wbytes = ((whi - wlo) * 8 < 0x7ffff000L) ? (unsigned)((whi - wlo) * 8) : 0u;
     return fz;
 }
 
@@ -2222,7 +2274,7 @@ int adi_explicit_sweep0(int variant, const double *d_T, long valid_lo, long vali
 {
     ADI_REQUIRE(valid_lo <= 0 && valid_hi >= (long)(nx - 1) * (plane_stride ? plane_stride : (long)ny * nz) + (long)ny * nz,
                 "adi_explicit_sweep0: the readable range [%ld, %ld) does not cover the box", valid_lo, valid_hi);
-    const Fuse fz = make_fuse(nz, dx, dt, kappa, theta, valid_lo, valid_hi);
+    const Fuse fz = make_fuse(nx, ny, nz, plane_stride, dx, dt, kappa, theta, valid_lo, valid_hi);
     const double gam = kappa * dt / (dx * dx);   // adi3d_numba_coeff.py:292
     return sweep_entry(0, variant, d_T, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
                        sparse, theta, gam, dt, Tinf, d_out, d_xlo, d_xhi, d_work, work_bytes, stream, &fz);
@@ -2274,7 +2326,7 @@ int adi_explicit_condense0(int variant, const double *d_T, long valid_lo, long v
 {
     ADI_REQUIRE(valid_lo <= 0 && valid_hi >= (long)(nx - 1) * (plane_stride ? plane_stride : (long)ny * nz) + (long)ny * nz,
                 "adi_explicit_condense0: the readable range [%ld, %ld) does not cover the box", valid_lo, valid_hi);
-    const Fuse fz = make_fuse(nz, dx, dt, kappa, theta, valid_lo, valid_hi);
+    const Fuse fz = make_fuse(nx, ny, nz, plane_stride, dx, dt, kappa, theta, valid_lo, valid_hi);
     const double gam = kappa * dt / (dx * dx);
     return condense_entry(0, variant, d_T, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
                           sparse, theta, gam, dt, Tinf, d_cond, d_work, work_bytes, stream, &fz);

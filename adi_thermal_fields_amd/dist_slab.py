@@ -191,6 +191,32 @@ class HipEngine:
         self.check(self.lib.adi_sweep_condense(*self._args(axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf),
                                                h._p(cond), h._p(w), w.numel(), h._stream()))
 
+    # explicit stage folded into the axis-0 sweep / condensation (ABI v7).  The box (L.nx, L.ny, L.nz) starts at plane
+    # i0, row j0 of the extended state T_ext; neighbours outside the box are read from T_ext itself.
+    def fused_supported(self, nx, ny, nz, sx, cond_pass):
+        return bool(self.lib.adi_explicit_fused_supported(nx, ny, nz, sx, 1 if cond_pass else 0))
+
+    def _fused_args(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf):
+        h = self.hip
+        tv = T_ext[i0:i0 + L.nx, j0:j0 + L.ny, :]
+        vlo, vhi = h.valid_range(tv)
+        return (variant, h._p(tv), vlo, vhi, h._p(flags), h._p(pack[0]), h._p(pack[1]), h._p(pack[2]), h._p(pack[3]),
+                L.nx, L.ny, L.nz, L.sx, 1, dx, dt, kappa, theta, float(Tinf))
+
+    def sweep0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, t_out, xlo=None, xhi=None):
+        h = self.hip
+        w = self._workspace(L)
+        self.check(self.lib.adi_explicit_sweep0(*self._fused_args(variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa,
+                                                                  theta, Tinf),
+                                                h._p(t_out), h._p(xlo), h._p(xhi), h._p(w), w.numel(), h._stream()))
+
+    def condense0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, cond):
+        h = self.hip
+        w = self._workspace(L)
+        self.check(self.lib.adi_explicit_condense0(*self._fused_args(variant, L, T_ext, i0, j0, flags, pack, dx, dt,
+                                                                     kappa, theta, Tinf),
+                                                   h._p(cond), h._p(w), w.numel(), h._stream()))
+
     def interface(self, cond_all, world, rank, nlines, xlo, xhi):
         h = self.hip
         self.check(self.lib.adi_interface_solve(h._p(cond_all), world, rank, nlines, h._p(xlo), h._p(xhi),
@@ -211,8 +237,6 @@ def _interior(t_ext):
 class SlabStepper:
     """One rank's slab.  step(T) takes / returns the LOCAL (nxl, ny, nz) field (DeviceField, torch tensor or
     NumPy array); the state stays in HBM when fed back what step() returned."""
-
-    stage_names = ['halo+explicit', 'sweep_axis0_distributed', 'sweep_axis1', 'sweep_axis2_contig']
 
     def __init__(self, mask_local, dx, mat, params, Tinf=0.0, dir_mask=None, dir_value=None, neumann=None,
                  robin_h=None, comm=None, engine=None):
@@ -235,6 +259,8 @@ class SlabStepper:
         self._a0_key, self._a0, self.axis0_mode = None, None, None
         self._no_overlap, self._force_exact = False, False
         self._allow_window = True                  # False keeps 'window' plans off (whole-slab condensation only)
+        self._allow_fused = True                   # False: explicit stage as its own kernel (R0 through HBM)
+        self.fused = False
         self._comm_stream, self._use_streams = None, False
         self._halo_ready, self._halo_event = None, None
         self._gam = 0.0
@@ -290,13 +316,36 @@ class SlabStepper:
         self.flags_int = _interior(self.flags_ext)
 
     @property
+    def stage_names(self):
+        if self._fused_now():
+            return ['halo+explicit+sweep_axis0_distributed', 'sweep_axis1', 'sweep_axis2_contig']
+        return ['halo+explicit', 'sweep_axis0_distributed', 'sweep_axis1', 'sweep_axis2_contig']
+
+    @property
     def stage_bytes_per_cell(self):
-        """algorithmic HBM bytes per local cell of the four stages (pass A re-reads the inputs of the rows it covers)"""
+        """algorithmic HBM bytes per local cell of the stages (pass A re-reads the inputs of the rows it covers)"""
         bpc = self._bpc
         frac = 0.0
         if self.world > 1:
             frac = 1.0 if (self._a0 is None or self._a0['mode'] != 'window') else min(1.0, 2.0 * self._a0['K'] / self.nxl)
+        if self._fused_now():
+            return [bpc[0] + frac * (bpc[0] - 8), bpc[1], bpc[2]]
         return [self._explicit_bpc, bpc[0] + frac * (bpc[0] - 8), bpc[1], bpc[2]]
+
+    def _fused_supported(self, K):
+        """explicit stage folded into pass B (whole slab) and, with neighbours, into pass A on K planes"""
+        E, L = self.engine, self.Lint
+        if not self._allow_fused or not hasattr(E, 'sweep0_fused'):
+            return False
+        ok = E.fused_supported(self.nxl, self.ny, self.nz, L.sx, False)
+        if self.world > 1:
+            ok = ok and E.fused_supported(K, self.ny, self.nz, L.sx, True)
+        return bool(ok)
+
+    def _fused_now(self):
+        if self.world == 1:
+            return self._fused_supported(self.nxl)
+        return bool(self._a0['fused']) if self._a0 is not None else self._fused_supported(self.nxl)
 
     @staticmethod
     def local_numpy(T):
@@ -354,7 +403,8 @@ class SlabStepper:
         """-> plan dict for the current (dt, theta, mask): mode 'exact' | 'window' (first/last K planes) |
         'slab' (the whole slab is its own window).  Collective: every rank calls it at the same step."""
         prm = self.params
-        key = (float(prm.dt), float(prm.theta), self._mask_version, self._force_exact, self._no_overlap)
+        key = (float(prm.dt), float(prm.theta), self._mask_version, self._force_exact, self._no_overlap,
+               self._allow_fused, self._allow_window)
         if self._a0_key == key:
             return self._a0
         E, v = self.engine, self.variant
@@ -411,33 +461,40 @@ class SlabStepper:
                 b['next_lo'] = E.vec(2 * n)        # (gF, aF) of the slab above
             bufs.append(b)
         plan['chunks'] = bufs
+        plan['fused'] = self._fused_supported(plan['K'])     # the same on every rank (it depends on sizes only...
+        if self.world > 1:                                   # ...but slabs may differ by two planes: make it collective)
+            flag.fill_(1.0 if plan['fused'] else 0.0)
+            self.comm.all_gather(allf, flag)
+            plan['fused'] = bool(float(allf.min()) >= 1.0)
         self._a0_key, self._a0 = key, plan
         self.axis0_mode = plan['mode']
         return plan
 
+    def _condense_box(self, plan, L, src, p0, p1, j0, j1, cond):
+        """pass A on planes [p0, p1), rows [j0, j1) of the slab.  src: the explicit stage's output (interior view) or,
+        when the explicit stage is folded into the pass, the extended state itself."""
+        E, prm, v = self.engine, self.params, self.variant
+        cut = lambda t: None if t is None else t[p0:p1, j0:j1, :]
+        fl, pk = cut(self.flags_int), tuple(cut(t) for t in self.packs_int[0])
+        if plan['fused']:
+            E.condense0_fused(v, L, src, 1 + p0, j0, fl, pk, self.dx, prm.dt, self._kappa, prm.theta, self.Tinf, cond)
+        else:
+            E.condense(0, v, L, cut(src), fl, pk, prm.theta, self._gam, prm.dt, self.Tinf, cond)
+
     def _condense_windows(self, plan, Ai, b):
         """pass A on one chunk of lines: the condensations this rank's neighbours need"""
-        E, prm, v, K = self.engine, self.params, self.variant, plan['K']
-        gam = self._gam
+        K, n = plan['K'], self.nxl
         j0, j1 = b['j0'], b['j1']
-        fl, pk = self.flags_int, self.packs_int[0]
-        cut = lambda t, p0, p1: None if t is None else t[p0:p1, j0:j1, :]
         if plan['mode'] == 'exact':
-            E.condense(0, v, b['Lb'], cut(Ai, 0, self.nxl), cut(fl, 0, self.nxl), tuple(cut(t, 0, self.nxl) for t in pk),
-                       prm.theta, gam, prm.dt, self.Tinf, b['cond'])
-            return
-        n = self.nxl
-        if plan['mode'] == 'slab':
+            self._condense_box(plan, b['Lb'], Ai, 0, n, j0, j1, b['cond'])
+        elif plan['mode'] == 'slab':
             if self.world > 1:
-                E.condense(0, v, b['Lb'], cut(Ai, 0, n), cut(fl, 0, n), tuple(cut(t, 0, n) for t in pk), prm.theta, gam,
-                           prm.dt, self.Tinf, b['cond_hi'])
-            return
-        if self.rank > 0:
-            E.condense(0, v, b['Lc'], cut(Ai, 0, K), cut(fl, 0, K), tuple(cut(t, 0, K) for t in pk), prm.theta, gam,
-                       prm.dt, self.Tinf, b['cond_lo'])
-        if self.rank < self.world - 1:
-            E.condense(0, v, b['Lc'], cut(Ai, n - K, n), cut(fl, n - K, n), tuple(cut(t, n - K, n) for t in pk), prm.theta,
-                       gam, prm.dt, self.Tinf, b['cond_hi'])
+                self._condense_box(plan, b['Lb'], Ai, 0, n, j0, j1, b['cond_hi'])
+        else:
+            if self.rank > 0:
+                self._condense_box(plan, b['Lc'], Ai, 0, K, j0, j1, b['cond_lo'])
+            if self.rank < self.world - 1:
+                self._condense_box(plan, b['Lc'], Ai, n - K, n, j0, j1, b['cond_hi'])
 
     def _exchange_interface(self, plan, b):
         if plan['mode'] == 'exact':
@@ -458,8 +515,12 @@ class SlabStepper:
             E.interface_pair(b['cond_lo'], b['cond_hi'], b['prev_hi'] if self.rank > 0 else None,
                              b['next_lo'] if self.rank < self.world - 1 else None, b['nl'], b['xlo'], b['xhi'])
         cut = lambda t: None if t is None else t[:, j0:j1, :]
-        E.sweep(0, v, b['Lb'], cut(Ai), cut(fl), tuple(cut(t) for t in pk), prm.theta, self._gam, prm.dt, self.Tinf,
-                cut(Bi), b['xlo'], b['xhi'])
+        if plan['fused']:
+            E.sweep0_fused(v, b['Lb'], Ai, 1, j0, cut(fl), tuple(cut(t) for t in pk), self.dx, prm.dt, self._kappa,
+                           prm.theta, self.Tinf, cut(Bi), b['xlo'], b['xhi'])
+        else:
+            E.sweep(0, v, b['Lb'], cut(Ai), cut(fl), tuple(cut(t) for t in pk), prm.theta, self._gam, prm.dt, self.Tinf,
+                    cut(Bi), b['xlo'], b['xhi'])
 
     def _axis0_pipeline(self, plan, Ai, Bi, condensed=False):
         """pass A, exchange, interface solve and pass B over the chunks of lines; with RCCL the exchange of chunk c
@@ -521,7 +582,7 @@ class SlabStepper:
         the rest of the last sweep runs.  (The other forms start with the planes that need no halo, which hides
         the exchange just as well.)"""
         E, prm, mat = self.engine, self.params, self.mat
-        kappa = mat.k / (mat.rho * mat.cp)                       # adi3d_numba_coeff.py:292
+        kappa = self._kappa = mat.k / (mat.rho * mat.cp)         # adi3d_numba_coeff.py:292
         gam = self._gam = kappa * prm.dt / (self.dx * self.dx)
         kind = 'torch' if isinstance(T, torch.Tensor) else ('numpy' if isinstance(T, np.ndarray) else 'field')
         Text = self._load_state(T)
@@ -530,12 +591,16 @@ class SlabStepper:
         Ai, Bi, Oi = _interior(A), _interior(B), _interior(nxt)
         v, Li, fl = self.variant, self.Lint, self.flags_int
         nl = self.nxl
+        ne = 0
 
-        def mark(i):
+        def mark():
+            nonlocal ne
             if events is not None:
-                events[i].record()
-        mark(0)
+                events[ne].record()
+            ne += 1
+        mark()
         plan = self._plan_axis0(_interior(Text), gam) if self.world > 1 else None
+        fused = plan['fused'] if plan is not None else self._fused_supported(nl)
         streams = self._streams() and self.world > 1
         main = torch.cuda.current_stream() if streams else None
         ex = lambda b, e: E.explicit(self.Lext, Text, self.flags_ext, self.dx, prm.dt, kappa, prm.theta, A, b, e)
@@ -557,9 +622,19 @@ class SlabStepper:
         self._halo_ready = None
 
         # 2. explicit stage, 3. axis-0 sweep
-        if self.world == 1:
+        if fused:
+            # R0 never reaches HBM: both passes of the axis-0 sweep evaluate it from the state (halo planes included,
+            # so they must have landed; in an nsub loop they were sent while the previous step's last sweep ran)
+            if self.world == 1:
+                E.sweep0_fused(v, Li, Text, 1, 0, fl, self.packs_int[0], self.dx, prm.dt, kappa, prm.theta, self.Tinf, Bi)
+            else:
+                if halo_ev is not None and streams:
+                    main.wait_event(halo_ev)
+                ev_x = self._axis0_pipeline(plan, Text, Bi)
+                self._axis0_finish(plan, Text, Bi, ev_x)
+        elif self.world == 1:
             ex(1, nl + 1)
-            mark(1)
+            mark()
             E.sweep(0, v, Li, Ai, fl, self.packs_int[0], prm.theta, gam, prm.dt, self.Tinf, Bi)
         elif plan['mode'] == 'window':
             # the boundary windows first: their condensation travels while the middle planes are computed
@@ -573,7 +648,7 @@ class SlabStepper:
             ev_x = self._axis0_pipeline(plan, Ai, Bi)
             if 2 * K < nl:
                 ex(K + 1, nl - K + 1)
-            mark(1)
+            mark()
             self._axis0_finish(plan, Ai, Bi, ev_x)
         else:
             # the planes that touch no halo run while the halo planes are in flight
@@ -586,18 +661,19 @@ class SlabStepper:
                 if halo_ev is not None and streams:
                     main.wait_event(halo_ev)
                 ex(1, nl + 1)
-            mark(1)
+            mark()
             ev_x = self._axis0_pipeline(plan, Ai, Bi)
             self._axis0_finish(plan, Ai, Bi, ev_x)
-        mark(2)
+        mark()
         # 4. local sweeps
         E.sweep(1, v, Li, Bi, fl, self.packs_int[1], prm.theta, gam, prm.dt, self.Tinf, Ai)
-        mark(3)
+        mark()
         pk2 = self.packs_int[2]
         sw2 = lambda p0, p1: E.sweep(2, v, E.layout(p1 - p0, self.ny, self.nz, Li.sx), Ai[p0:p1], fl[p0:p1],
                                      tuple(None if t is None else t[p0:p1] for t in pk2), prm.theta, gam, prm.dt,
                                      self.Tinf, Oi[p0:p1])
-        if prefetch_halo and self.world > 1 and nl >= 4 and plan['mode'] == 'window':
+        # the fused passes and the 'window' form start with planes that need the halos: send them early
+        if prefetch_halo and self.world > 1 and nl >= 4 and (plan['mode'] == 'window' or fused):
             sw2(0, 1); sw2(nl - 1, nl)                        # the two planes the neighbours need
             if streams:
                 ev0 = torch.cuda.Event(); ev0.record(main)
@@ -612,7 +688,7 @@ class SlabStepper:
             sw2(1, nl - 1)
         else:
             sw2(0, nl)
-        mark(4)
+        mark()
         self._cur ^= 1
         if kind == 'numpy':
             return Oi.cpu().contiguous().numpy()

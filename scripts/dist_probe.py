@@ -40,18 +40,20 @@ def main():
     import os
     st._force_exact = bool(int(os.environ.get('PROBE_EXACT', '0')))
     pre = bool(int(os.environ.get('PROBE_PREFETCH', '1')))
+    st._allow_fused = bool(int(os.environ.get('PROBE_FUSED', '1')))
     for _ in range(3):
         T = st.step(T, prefetch_halo=pre)
     torch.cuda.synchronize()
-    print('axis-0 interface form:', st.axis0_mode, 'K =', st._a0['K'], 'chunks =', len(st._a0['chunks']))
+    print('axis-0 interface form:', st.axis0_mode, 'K =', st._a0['K'], 'chunks =', len(st._a0['chunks']), 'fused =', st._a0['fused'])
     K = 10
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(K)]
+    nst = len(st.stage_names)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(K)]
     t0 = time.perf_counter()
     for s in range(K):
         T = st.step(T, events=ev[s], prefetch_halo=pre)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K * 1e3
-    ms = np.array([[ev[s][i].elapsed_time(ev[s][i + 1]) for i in range(4)] for s in range(K)]).mean(axis=0)
+    ms = np.array([[ev[s][i].elapsed_time(ev[s][i + 1]) for i in range(nst)] for s in range(K)]).mean(axis=0)
     print('per-rank step %.3f ms (wall); stages %s' % (dt, dict(zip(st.stage_names, np.round(ms, 3)))))
 
 

@@ -82,7 +82,8 @@ class CpuEngine:
         return torch.zeros(n, dtype=torch.float64)
 
     def build_flags(self, L, mask_ext):
-        return torch.from_numpy(_flags(mask_ext.numpy()))
+        self._flags_ext = torch.from_numpy(_flags(mask_ext.numpy()))
+        return self._flags_ext
 
     def build_packs(self, L, mask_ext, flags_ext, dx, mat, dir_mask, dir_value, neumann, robin_h):
         grid = orc.Grid3D(L.nx, L.ny, L.nz, dx, mask_ext.numpy().astype(bool))
@@ -99,6 +100,30 @@ class CpuEngine:
         grid = orc.Grid3D(L.nx, L.ny, L.nz, dx, mask)
         out_ext.copy_(torch.from_numpy(orc.explicit_rhs(np.nan_to_num(T_ext.numpy()), grid, orc.Material(1.0, 1.0, kappa),
                                                         orc.Params(dt, theta))))
+
+    # fused explicit + axis-0 passes of the product engine: here simply the explicit stage on the whole extended
+    # slab followed by the plain pass on the box
+    def fused_supported(self, nx, ny, nz, sx, cond_pass):
+        return True
+
+    def _r0_box(self, L, T_ext, i0, j0, flags, dx, dt, kappa, theta):
+        ne = T_ext.shape[0]
+        # flags of the box carry the halo coupling bits; rebuild a mask for the whole extended slab from T_ext's shape
+        fl_ext = self._flags_ext
+        Le = CpuLayout(ne, T_ext.shape[1], T_ext.shape[2])
+        r0 = torch.zeros(Le.shape, dtype=torch.float64)
+        self.explicit(Le, T_ext, fl_ext, dx, dt, kappa, theta, r0)
+        return r0[i0:i0 + L.nx, j0:j0 + L.ny, :].contiguous()
+
+    def sweep0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, t_out, xlo=None, xhi=None):
+        r0 = self._r0_box(L, T_ext, i0, j0, flags, dx, dt, kappa, theta)
+        tmp = torch.zeros(L.shape, dtype=torch.float64)
+        self.sweep(0, variant, L, r0, flags, pack, theta, kappa * dt / (dx * dx), dt, Tinf, tmp, xlo, xhi)
+        t_out.copy_(tmp)
+
+    def condense0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, cond):
+        r0 = self._r0_box(L, T_ext, i0, j0, flags, dx, dt, kappa, theta)
+        self.condense(0, variant, L, r0, flags, pack, theta, kappa * dt / (dx * dx), dt, Tinf, cond)
 
     def sweep(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, xlo=None, xhi=None):
         a, b, c, d = _line_systems(axis, t_in, flags, pack, theta, gam, dt, Tinf)

@@ -60,6 +60,7 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q, opts=None):
                                    comm=dist_slab.TorchDistComm(), engine=CpuEngine())
         st._force_exact = bool(opts.get('force_exact', False))
         st._allow_window = bool(opts.get('allow_window', True))
+        st._allow_fused = bool(opts.get('allow_fused', True))
         T = torch.from_numpy(np.ascontiguousarray(c['T0'][i0:i1]))
         for s in range(nsteps):
             T = st.step(T, prefetch_halo=bool(opts.get('prefetch', False)) and s + 1 < nsteps)
@@ -68,9 +69,9 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q, opts=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,case_name', [(2, 'holes_mixed'), (3, 'kat2'), (2, 'dirichlet_only_gamma07'),
-                                             (2, 'slab_chunks')])
-def test_slab_decomposition_matches_single_domain(world, case_name):
+@pytest.mark.parametrize('world,case_name,fused', [(2, 'holes_mixed', True), (2, 'holes_mixed', False), (3, 'kat2', True),
+                                                   (2, 'dirichlet_only_gamma07', False), (2, 'slab_chunks', True)])
+def test_slab_decomposition_matches_single_domain(world, case_name, fused):
     sys.path.insert(0, os.path.dirname(HERE))
     from oracle import adi_oracle as orc
     from helpers import run_cart_case, rel_linf
@@ -83,7 +84,8 @@ def test_slab_decomposition_matches_single_domain(world, case_name):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case_name, sizes, nsteps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case_name, sizes, nsteps, q, dict(allow_fused=fused)))
+             for r in range(world)]
     for p in procs:
         p.start()
     parts = {r: t for r, t, _ in (q.get(timeout=120) for _ in range(world))}
@@ -117,6 +119,8 @@ def _run_world(world, case_name, sizes, nsteps, opts):
     (3, 72, dict(prefetch=True), 'slab'),            # 24 planes: the whole slab is the window
     (2, 128, dict(allow_window=False), 'slab'),
     (2, 128, dict(force_exact=True, prefetch=True), 'exact'),
+    (2, 128, dict(prefetch=True, allow_fused=False), 'window'),
+    (3, 72, dict(prefetch=True, allow_fused=False), 'slab'),
 ])
 def test_neighbour_only_interface_matches_single_domain(world, nx, opts, mode):
     """thick slabs / small dt: the reduced system splits into 2x2 neighbour systems (dist_slab docstring); the result
