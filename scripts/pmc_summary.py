@@ -27,10 +27,16 @@ def pick(sub):
     # the dense general-pack instantiations (<.., true, true>) are bench.py's separate 42 B/cell measurements
     tot = [v['hbm_bytes'] for k, v in kern.items() if sub in k and 'true, true>' not in k]
     return sum(tot) if tot else None
+def pick_fused(sub, fused):
+    # FUSE is the last template argument of the strided kernels: <M, HAS_DIR, HAS_Q, FUSE>
+    tot = [v['hbm_bytes'] for k, v in kern.items() if sub in k and 'true, true,' not in k
+           and k.rstrip('>').endswith('true' if fused else 'false')]
+    return sum(tot) if tot else None
 out = dict(note='HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of wide reads); '
-                'sweeps = FAST kernel + GENERAL kernel on the queued units',
-           explicit=pick('k_explicit'), sweep_axis0=pick('k_sweep_strided'), sweep_axis1=pick('k_sweep_strided'),
-           sweep_axis2_contig=pick('k_sweep_contig'),
+                'sweeps = FAST kernel + GENERAL kernel on the queued units; keys are bench.py stage names',
+           explicit=pick('k_explicit'), sweep_axis0=pick_fused('k_sweep_strided', False),
+           sweep_axis1=pick_fused('k_sweep_strided', False), sweep_axis2_contig=pick('k_sweep_contig'),
            kernels=kern)
+out['explicit+sweep_axis0'] = pick_fused('k_sweep_strided', True)
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != 'kernels'}, indent=1))
