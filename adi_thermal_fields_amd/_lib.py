@@ -61,7 +61,16 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'adi_explicit_condense0': (c_int, [c_int, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double,
-                                       c_double, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                       c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'adi_axis0_dots_supported': (c_int, [c_int, c_int, c_int, c_long]),
+    'adi_axis0_dots_workspace': (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
+    'adi_axis0_dots_setup': (c_int, [c_int, c_double, c_double, c_void_p, c_void_p]),
+    'adi_axis0_classify': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
+    'adi_explicit_rhs_dots': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_double, c_double, c_double,
+                                      c_double, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'adi_axis0_dots_finish': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_double, c_double,
+                                      c_double, c_double, c_long, c_long, c_void_p, c_void_p]),
     'adi_interface_solve': (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
     'adi_interface_pair': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     'adi_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_pp, c_void_p, c_void_p,

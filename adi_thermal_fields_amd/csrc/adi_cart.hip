@@ -21,6 +21,8 @@
 // (< 1 flop/byte); no MFMA.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "adi_common.hpp"
 #include "adi_core.hpp"
 
@@ -72,6 +74,8 @@ struct Fuse {
     int kt, ny, kg;     // FAST kernel tile order: kt tiles per j-row, groups of kg k-tiles walked j-fastest (kg = 0: off)
     long wlo;           // FAST kernel: the buffer descriptor of the state covers [wlo, wlo + wbytes/8) relative to `in`
     unsigned wbytes;    // (0: the window would not fit 32-bit offsets, GENERAL kernel only)
+    double *r0_out;     // pass A only (may be null): R0 is also stored here (box layout of `in`), so that pass B can be
+                        // the plain sweep instead of evaluating the explicit stage a second time
 };
 
 // FUSE tile order: the j-neighbour rows a tile re-reads belong to the tiles of the adjacent j-rows; walking groups of kg
@@ -965,6 +969,11 @@ __device__ __forceinline__ void condense_tile_general(
         // aF, aL / cF, cL of the slab)
         SegRaw<M> R;
         load_segment_raw<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R, fz);
+        if (FUSE && fz.r0_out != nullptr) {
+#pragma unroll
+            for (int r = 0; r < M; ++r)
+                if (active && (r0 + r) < g.n) fz.r0_out[base + (long)(r0 + r) * g.stride] = R.vin[r];
+        }
 #pragma unroll
         for (int r = 0; r < M; ++r) assemble_one<M, HAS_DIR, HAS_Q>(R, r, g.lbit, s, a[r], b[r], c[r], d[r]);
     }
@@ -1042,6 +1051,14 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_condense_strid
         if (tid == 0) enqueue_unit(queue, (unsigned)tile);
         return;
     }
+    if constexpr (FUSE) {
+        if (fz.r0_out != nullptr) {
+            const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)(fz.r0_out + tbase), 0, 0x7fffffff,
+                                                                                0x00020000);
+#pragma unroll
+            for (int r = 0; r < M; ++r) buf_store_f64(rO, voff * 8u, (unsigned)r * (unsigned)(g.stride * 8), d[r]);
+        }
+    }
     double a0, b0, aS, bS, cS;
     fast_segment_ends<M, HAS_DIR, HAS_Q>(coeff, dval, qf, g, base, r0, f0, fS, dirS, s, d, a0, b0, aS, bS, cS);
     Cond ki;
@@ -1061,9 +1078,18 @@ template <bool HAS_DIR, bool HAS_Q>
 __global__ __launch_bounds__(256) void k_condense_generic(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    double *__restrict__ cond, long nlines, LineGeom g, long inner_stride, SweepScal s)
+    double *__restrict__ cond, long nlines, LineGeom g, long inner_stride, SweepScal s,
+    const unsigned *__restrict__ list = nullptr, long lb = 0, long nsel = 0)
 {
-    const long lid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // list != nullptr: only the listed lines that fall into [lb, lb + nsel), written to a [6][nsel] block
+    long lid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long oid = lid, ostr = nlines;
+    if (list != nullptr) {
+        if (lid >= (long)list[0]) return;
+        lid = list[1 + lid];
+        if (lid < lb || lid >= lb + nsel) return;
+        oid = lid - lb; ostr = nsel;
+    }
     if (lid >= nlines) return;
     const long o = lid / g.n_inner, kc = lid - o * g.n_inner;
     const long base = o * g.outer_stride + kc * inner_stride;
@@ -1095,8 +1121,8 @@ __global__ __launch_bounds__(256) void k_condense_generic(
         else { const double w = c * jp; jp = 1.0 / (b - w * anext); z = d - w * z; f2 = -w * f2; }
         anext = a;
     }
-    cond[lid] = z * jp; cond[nlines + lid] = a0 * jp; cond[2 * nlines + lid] = cn * (f2 * jp);
-    cond[3 * nlines + lid] = gL; cond[4 * nlines + lid] = aL; cond[5 * nlines + lid] = cL;
+    cond[oid] = z * jp; cond[ostr + oid] = a0 * jp; cond[2 * ostr + oid] = cn * (f2 * jp);
+    cond[3 * ostr + oid] = gL; cond[4 * ostr + oid] = aL; cond[5 * ostr + oid] = cL;
 }
 
 // K5c: interface solve.  cond_all: [nranks][6][nlines] (all-gathered).  For this rank, merge the slabs below
@@ -1407,11 +1433,16 @@ __global__ __launch_bounds__(256) void k_explicit_v3(const double *__restrict__ 
 // (96 VGPRs, 5 waves/SIMD) although those re-read twice as many j-halo rows: the stage is bound by loads in flight per
 // wave, not by traffic -- a variant that shared the halo rows of a 16/32-row block tile through LDS (one barrier per
 // plane) cut the traffic and ran no faster, so it was dropped; the re-read rows are served by L2 / Infinity Cache.
-template <int JT>
+// DOTS (slab decomposition, pass A folded into the explicit stage): while marching, every line's R0 values are also
+// accumulated into the two dot products the reduced interface system needs from a line whose rows are uniform --
+// su = sum_i u[i] R0_i, sv = sum_i u[n-1-i] R0_i with u = first column of tridiag(-tg, 1+2tg, -tg)^-1 (wu, n values) --
+// one partial pair per chunk of planes: part[chunk][2][ny*nz], summed in order by k_dots_finish.
+template <int JT, bool DOTS = false>
 __global__ __launch_bounds__(256) void k_explicit_v5(const double *__restrict__ T, const uint8_t *__restrict__ flags,
                                                      double *__restrict__ R0, Lay L, double invdx2, double f,
                                                      int jslab, int ktiles, int ichunk, long ntiles, int i_begin,
-                                                     int i_end)
+                                                     int i_end, const double *__restrict__ wu = nullptr,
+                                                     double *__restrict__ part = nullptr)
 {
 #pragma clang fp contract(off)
     const int nx = L.nx, ny = L.ny, nz = L.nz;
@@ -1473,9 +1504,17 @@ __global__ __launch_bounds__(256) void k_explicit_v5(const double *__restrict__ 
     load_plane(i0, tc);
     load_plane(i0 + 1, tp);
     load_meta(i0, fl, ke, hm, hp);
+    double2 su[DOTS ? JT : 1], sv[DOTS ? JT : 1];
+    if (DOTS) {
+#pragma unroll
+        for (int r = 0; r < JT; ++r) { su[r] = zero2; sv[r] = zero2; }
+    }
+    const int ndots = i_end - i_begin;
     for (int i = i0; i < i1; ++i) {
         const long p = (long)i * sx + pbase;
         const bool more = i + 1 < i1;
+        double wa = 0.0, wb = 0.0;
+        if (DOTS) { wa = wu[i - i_begin]; wb = wu[ndots - 1 - (i - i_begin)]; }     // block-uniform: scalar loads
         if (more) {
             load_plane(i + 2, tq);
             load_meta(i + 1, fln, ken, hmn, hpn);
@@ -1510,6 +1549,10 @@ __global__ __launch_bounds__(256) void k_explicit_v5(const double *__restrict__ 
                 r1v = tc[r].y + f * ((L0 + L1) + L2);
             }
             if (kin && rin) *reinterpret_cast<double2 *>(R0 + q) = make_double2(r0v, r1v);
+            if (DOTS) {
+                su[r].x = __builtin_fma(wa, r0v, su[r].x); su[r].y = __builtin_fma(wa, r1v, su[r].y);
+                sv[r].x = __builtin_fma(wb, r0v, sv[r].x); sv[r].y = __builtin_fma(wb, r1v, sv[r].y);
+            }
         }
 #pragma unroll
         for (int r = 0; r < JT; ++r) {
@@ -1518,6 +1561,101 @@ __global__ __launch_bounds__(256) void k_explicit_v5(const double *__restrict__ 
         }
         hm = hmn; hp = hpn;
     }
+    if (DOTS) {
+        const long nlines = (long)ny * nz;
+        double *pu = part + (long)ic * 2 * nlines, *pv = pu + nlines;
+#pragma unroll
+        for (int r = 0; r < JT; ++r)
+            if (kin && j0 + r < jend) {
+                const long line = (long)(j0 + r) * nz + k0;
+                *reinterpret_cast<double2 *>(pu + line) = su[r];
+                *reinterpret_cast<double2 *>(pv + line) = sv[r];
+            }
+    }
+}
+
+// ---- pass A from the dot products (slab decomposition) -----------------------------------------------------------------
+// A line is "uniform" for the axis-0 sweep when its rows 1..n-2 are in the mask with both axis neighbours and are not
+// Dirichlet, its end rows are in the mask (not Dirichlet) with their inward neighbour, and at most one end row differs
+// from the interior row (line start/end, Robin coefficient).  cls[line] = 1 for those; the others are appended to
+// list[1..] (list[0] = count) and condensed by k_condense_generic from the stored R0.
+__global__ __launch_bounds__(256) void k_classify_lines0(const uint8_t *__restrict__ flags,
+                                                         const uint8_t *__restrict__ dmask, Lay L,
+                                                         uint8_t *__restrict__ cls, unsigned *__restrict__ list)
+{
+    const long nlines = (long)L.ny * L.nz;
+    const long lid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lid >= nlines) return;
+    const int n = L.nx;
+    bool ok = n >= 2;
+    unsigned f0 = 0, fn = 0;
+    for (int r = 0; r < n; ++r) {
+        const long p = (long)r * L.sx + lid;
+        const unsigned f = flags[p];
+        if (dmask != nullptr && dmask[p] != 0) ok = false;
+        if (r == 0) { f0 = f; ok = ok && ((f & 5u) == 5u); }                 // in mask, next row in mask
+        else if (r == n - 1) { fn = f; ok = ok && ((f & 3u) == 3u); }        // in mask, previous row in mask
+        else ok = ok && ((f & 7u) == 7u);
+    }
+    // an end row without its outward neighbour is a modified row (b = 1 + tg + dt*coeff): at most one per line
+    if (ok && !(f0 & 2u) && !(fn & 4u)) ok = false;
+    cls[lid] = ok ? 1 : 0;
+    if (!ok) list[1 + atomicAdd(&list[0], 1u)] = (unsigned)lid;
+}
+
+// cond[6][nsel] of the lines [lb, le) from the partial dot products (uniform lines only; the others keep what
+// k_condense_generic wrote).  Formulas: condense_uniform (adi_core.hpp) applied to the whole line.
+template <bool HAS_Q>
+__global__ __launch_bounds__(256) void k_dots_finish(const double *__restrict__ part, int nchunk,
+                                                     const double *__restrict__ wu, const uint8_t *__restrict__ cls,
+                                                     const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+                                                     const double *__restrict__ qf, Lay L, SweepScal s, long lb, long le,
+                                                     double *__restrict__ cond)
+{
+    const long nlines = (long)L.ny * L.nz, nsel = le - lb;
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nsel) return;
+    const long lid = lb + id;
+    if (!cls[lid]) return;
+    const int n = L.nx;
+    double gu = 0.0, gv = 0.0;
+    for (int c = 0; c < nchunk; ++c) {                      // fixed order: deterministic
+        gu += part[(long)c * 2 * nlines + lid];
+        gv += part[((long)c * 2 + 1) * nlines + lid];
+    }
+    const long pF = lid, pL = (long)(n - 1) * L.sx + lid;
+    const unsigned fF = flags[pF], fL = flags[pL];
+    const bool loF = (fF & 2u) != 0, hiL = (fL & 4u) != 0;   // the line continues below / above the slab
+    const double p0 = wu[0], pn = wu[n - 1];
+    const double bu = 1.0 + 2.0 * s.tg;
+    // right-hand side terms of the end rows beyond R0 (assemble_row): dt*q + dt*coeff*Tinf on axis-exposed cells
+    const double coF = loF ? 0.0 : coeff[pF], coL = hiL ? 0.0 : coeff[pL];
+    double xF = s.dt * coF * s.Tinf, xL = s.dt * coL * s.Tinf;
+    if (HAS_Q) { if (!loF) xF += s.dt * qf[pF]; if (!hiL) xL += s.dt * qf[pL]; }
+    gu += p0 * xF + pn * xL;                                 // (U^-1 d)_0
+    gv += pn * xF + p0 * xL;                                 // (U^-1 d)_{n-1}
+    const double a0 = loF ? -s.tg : 0.0, cn = hiL ? -s.tg : 0.0;
+    double gF, aF, cF, gL, aL, cL;
+    if (!loF) {            // row 0 modified: b0 = 1 + tg + dt*coF
+        const double delta = (1.0 + s.tg + s.dt * coF) - bu;
+        const double kappa = delta / (1.0 + delta * p0);
+        const double f1 = 1.0 - kappa * p0, kpl = kappa * pn;
+        gF = gu * f1;            gL = gv - kpl * gu;
+        aF = 0.0;                aL = 0.0;
+        cF = cn * (pn - kpl * p0); cL = cn * (p0 - kpl * pn);
+    } else if (!hiL) {     // row n-1 modified
+        const double delta = (1.0 + s.tg + s.dt * coL) - bu;
+        const double kappa = delta / (1.0 + delta * p0);
+        const double f1 = 1.0 - kappa * p0, kpl = kappa * pn;
+        gL = gv * f1;            gF = gu - kpl * gv;
+        cL = 0.0;                cF = 0.0;
+        aL = a0 * (pn - kpl * p0); aF = a0 * (p0 - kpl * pn);
+    } else {
+        gF = gu; gL = gv;
+        aF = a0 * p0; cF = cn * pn; aL = a0 * pn; cL = cn * p0;
+    }
+    cond[id] = gF; cond[nsel + id] = aF; cond[2 * nsel + id] = cF;
+    cond[3 * nsel + id] = gL; cond[4 * nsel + id] = aL; cond[5 * nsel + id] = cL;
 }
 
 // cell index -> (i, j, k, memory offset) for elementwise kernels over a padded-plane layout
@@ -2131,10 +2269,12 @@ int adi_explicit_rhs_planes(const double *d_T, const uint8_t *d_flags, int nx, i
         const long ntiles = (long)nslab * nchunk * ((jslab + jt5 - 1) / jt5) * ktiles;
         if (jt5 == 2)
             hipLaunchKernelGGL(k_explicit_v5<2>, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
-                               L, invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end);
+                               L, invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end, (const double *)nullptr,
+                               (double *)nullptr);
         else
             hipLaunchKernelGGL(k_explicit_v5<4>, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
-                               L, invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end);
+                               L, invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end, (const double *)nullptr,
+                               (double *)nullptr);
     } else if (fast && (ver == 3 || np != nx)) {
         const int jslab = (ny + 7) / 8;
         const int nslab = (ny + jslab - 1) / jslab;
@@ -2174,6 +2314,127 @@ int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, 
                      double dt, double kappa, double theta, double *d_R0, void *stream)
 {
     return adi_explicit_rhs_planes(d_T, d_flags, nx, ny, nz, plane_stride, dx, dt, kappa, theta, d_R0, 0, nx, stream);
+}
+
+static int variant_flags(int variant, bool *has_dir, bool *has_q);
+
+// ---- pass A folded into the explicit stage (slab decomposition) ------------------------------------------------------
+static int dots_ichunk(int np) { return np >= 512 ? 32 : (np / 16 < 4 ? 4 : np / 16); }
+
+int adi_axis0_dots_supported(int nx, int ny, int nz, long plane_stride)
+{
+    static int off = -1;
+    if (off < 0) off = getenv("ADI_NO_DOTS") ? 1 : 0;
+    Lay L;
+    if (off || make_lay(nx, ny, nz, plane_stride, &L) != ADI_OK) return 0;
+    return (nx >= 2 && nz % 2 == 0 && L.sx % 2 == 0) ? 1 : 0;      // the marching explicit kernel's own conditions
+}
+
+int adi_axis0_dots_workspace(int nx, int ny, int nz, size_t *part_bytes, size_t *list_bytes)
+{
+    ADI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && part_bytes && list_bytes, "adi_axis0_dots_workspace: bad argument");
+    const int ich = dots_ichunk(nx);
+    const long nchunk = (nx + ich - 1) / ich;
+    *part_bytes = (size_t)nchunk * 2 * (size_t)ny * nz * sizeof(double);
+    *list_bytes = ((size_t)ny * nz + 1) * sizeof(unsigned);
+    return ADI_OK;
+}
+
+int adi_axis0_dots_setup(int n, double theta, double gam, double *d_weights, void *stream)
+{
+    ADI_REQUIRE(n >= 2 && d_weights, "adi_axis0_dots_setup: bad argument");
+    // u = first column of tridiag(-tg, 1+2tg, -tg)^-1 (n x n): Thomas on e_0 in long double
+    const long double tg = (long double)theta * (long double)gam, b = 1.0L + 2.0L * tg;
+    std::vector<long double> cp(n), x(n);
+    std::vector<double> u(n);
+    long double piv = b;
+    cp[0] = -tg / piv; x[0] = 1.0L / piv;
+    for (int i = 1; i < n; ++i) {
+        piv = b + tg * cp[i - 1];
+        cp[i] = -tg / piv;
+        x[i] = (tg * x[i - 1]) / piv;
+    }
+    for (int i = n - 2; i >= 0; --i) x[i] -= cp[i] * x[i + 1];
+    for (int i = 0; i < n; ++i) u[i] = (double)x[i];
+    ADI_HIP_TRY(hipMemcpyAsync(d_weights, u.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, as_stream(stream)));
+    ADI_HIP_TRY(hipStreamSynchronize(as_stream(stream)));      // u lives on this stack frame
+    return ADI_OK;
+}
+
+int adi_axis0_classify(const uint8_t *d_flags, const uint8_t *d_dir_mask, int nx, int ny, int nz, long plane_stride,
+                       uint8_t *d_cls, unsigned *d_list, void *stream)
+{
+    ADI_REQUIRE(d_flags && d_cls && d_list, "adi_axis0_classify: null argument");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    hipStream_t st = as_stream(stream);
+    ADI_HIP_TRY(hipMemsetAsync(d_list, 0, sizeof(unsigned), st));
+    const long nlines = (long)ny * nz;
+    hipLaunchKernelGGL(k_classify_lines0, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, st, d_flags, d_dir_mask, L,
+                       d_cls, d_list);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+int adi_explicit_rhs_dots(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride,
+                          double dx, double dt, double kappa, double theta, double *d_R0, int i_begin, int i_end,
+                          const double *d_weights, double *d_part, void *stream)
+{
+    ADI_REQUIRE(d_T && d_flags && d_R0 && d_weights && d_part, "adi_explicit_rhs_dots: null argument");
+    ADI_REQUIRE(d_T != d_R0, "adi_explicit_rhs_dots: output aliases input");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    ADI_REQUIRE(i_begin >= 0 && i_end <= nx && i_end - i_begin >= 2, "adi_explicit_rhs_dots: bad plane range [%d, %d)",
+                i_begin, i_end);
+    ADI_REQUIRE((nz % 2 == 0) && (L.sx % 2 == 0) && ((((uintptr_t)d_T | (uintptr_t)d_R0 | (uintptr_t)d_part) & 15) == 0) &&
+                    (((uintptr_t)d_flags & 1) == 0),
+                "adi_explicit_rhs_dots: needs even nz / plane stride and 16-byte aligned fields");
+    const int np = i_end - i_begin;
+    const int jslab = (ny + 7) / 8, nslab = (ny + jslab - 1) / jslab, ktiles = (nz + 511) / 512;
+    const int ichunk = dots_ichunk(np), nchunk = (np + ichunk - 1) / ichunk;
+    const long ntiles = (long)nslab * nchunk * ((jslab + 1) / 2) * ktiles;
+    hipLaunchKernelGGL((k_explicit_v5<2, true>), dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
+                       L, 1.0 / (dx * dx), dt * kappa * (1.0 - theta), jslab, ktiles, ichunk, ntiles, i_begin, i_end,
+                       d_weights, d_part);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+int adi_axis0_dots_finish(int variant, const double *d_part, const double *d_weights, const uint8_t *d_cls,
+                          const unsigned *d_list, const double *d_R0, const uint8_t *d_flags, const double *d_coeff,
+                          const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny,
+                          int nz, long plane_stride, double theta, double gam, double dt, double Tinf, long line_begin,
+                          long line_end, double *d_cond, void *stream)
+{
+    bool has_dir, has_q;
+    if (int rc = variant_flags(variant, &has_dir, &has_q)) return rc;
+    ADI_REQUIRE(d_part && d_weights && d_cls && d_list && d_R0 && d_flags && d_coeff && d_cond,
+                "adi_axis0_dots_finish: null argument");
+    ADI_REQUIRE(!has_dir || (d_dir_mask && d_dir_val), "adi_axis0_dots_finish: variant needs Dirichlet arrays");
+    ADI_REQUIRE(!has_q || d_qflux, "adi_axis0_dots_finish: variant needs the flux array");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    const long nlines = (long)ny * nz;
+    ADI_REQUIRE(line_begin >= 0 && line_end <= nlines && line_begin < line_end, "adi_axis0_dots_finish: bad line range");
+    SweepScal s;
+    s.tg = theta * gam; s.dt = dt; s.Tinf = Tinf; s.sparse = 0;
+    hipStream_t st = as_stream(stream);
+    const long nsel = line_end - line_begin;
+    const int nchunk = (nx + dots_ichunk(nx) - 1) / dots_ichunk(nx);
+    const unsigned grid = (unsigned)((nsel + 255) / 256);
+    if (has_q) hipLaunchKernelGGL((k_dots_finish<true>), dim3(grid), dim3(256), 0, st, d_part, nchunk, d_weights, d_cls, d_flags, d_coeff, d_qflux, L, s, line_begin, line_end, d_cond);
+    else hipLaunchKernelGGL((k_dots_finish<false>), dim3(grid), dim3(256), 0, st, d_part, nchunk, d_weights, d_cls, d_flags, d_coeff, d_qflux, L, s, line_begin, line_end, d_cond);
+    // the lines that are not uniform: the serial two-recurrence condensation from the stored R0 (grid sized for all
+    // lines; the kernel returns beyond the list's count)
+    long inner_stride;
+    const LineGeom g = line_geom(0, L, &inner_stride);
+    const unsigned gl = (unsigned)((nlines + 255) / 256);
+    if (has_dir && has_q) hipLaunchKernelGGL((k_condense_generic<true, true>), dim3(gl), dim3(256), 0, st, d_R0, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, d_cond, nlines, g, inner_stride, s, d_list, line_begin, nsel);
+    else if (has_q) hipLaunchKernelGGL((k_condense_generic<false, true>), dim3(gl), dim3(256), 0, st, d_R0, d_flags, d_coeff, nullptr, nullptr, d_qflux, d_cond, nlines, g, inner_stride, s, d_list, line_begin, nsel);
+    else if (has_dir) hipLaunchKernelGGL((k_condense_generic<true, false>), dim3(gl), dim3(256), 0, st, d_R0, d_flags, d_coeff, d_dir_mask, d_dir_val, nullptr, d_cond, nlines, g, inner_stride, s, d_list, line_begin, nsel);
+    else hipLaunchKernelGGL((k_condense_generic<false, false>), dim3(gl), dim3(256), 0, st, d_R0, d_flags, d_coeff, nullptr, nullptr, nullptr, d_cond, nlines, g, inner_stride, s, d_list, line_begin, nsel);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
 }
 
 int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, long plane_stride, size_t *bytes)
@@ -2247,6 +2508,7 @@ static Fuse make_fuse(int nx, int ny, int nz, long plane_stride, double dx, doub
     fz.vlo = valid_lo;
     fz.vhi = valid_hi;
     fz.kt = 0; fz.ny = 0; fz.kg = 0;
+    fz.r0_out = nullptr;
     // window of the state the FAST kernel's buffer descriptor covers: the box, one plane + one row + one tile around it
     const long sx = plane_stride ? plane_stride : (long)ny * nz;
     const long box_end = (long)(nx - 1) * sx + (long)ny * nz;
@@ -2321,12 +2583,14 @@ int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t 
 int adi_explicit_condense0(int variant, const double *d_T, long valid_lo, long valid_hi, const uint8_t *d_flags,
                            const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
                            const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse, double dx,
-                           double dt, double kappa, double theta, double Tinf, double *d_cond, void *d_work,
-                           size_t work_bytes, void *stream)
+                           double dt, double kappa, double theta, double Tinf, double *d_cond, double *d_R0_out,
+                           void *d_work, size_t work_bytes, void *stream)
 {
     ADI_REQUIRE(valid_lo <= 0 && valid_hi >= (long)(nx - 1) * (plane_stride ? plane_stride : (long)ny * nz) + (long)ny * nz,
                 "adi_explicit_condense0: the readable range [%ld, %ld) does not cover the box", valid_lo, valid_hi);
-    const Fuse fz = make_fuse(nx, ny, nz, plane_stride, dx, dt, kappa, theta, valid_lo, valid_hi);
+    ADI_REQUIRE(d_R0_out != d_T, "adi_explicit_condense0: R0 output aliases the state");
+    Fuse fz = make_fuse(nx, ny, nz, plane_stride, dx, dt, kappa, theta, valid_lo, valid_hi);
+    fz.r0_out = d_R0_out;
     const double gam = kappa * dt / (dx * dx);
     return condense_entry(0, variant, d_T, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
                           sparse, theta, gam, dt, Tinf, d_cond, d_work, work_bytes, stream, &fz);

@@ -210,12 +210,44 @@ class HipEngine:
                                                                   theta, Tinf),
                                                 h._p(t_out), h._p(xlo), h._p(xhi), h._p(w), w.numel(), h._stream()))
 
-    def condense0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, cond):
+    def condense0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, cond, r0_out=None):
+        """r0_out (optional, a view of the box in an array laid out like T_ext): also receives R0"""
         h = self.hip
         w = self._workspace(L)
         self.check(self.lib.adi_explicit_condense0(*self._fused_args(variant, L, T_ext, i0, j0, flags, pack, dx, dt,
                                                                      kappa, theta, Tinf),
-                                                   h._p(cond), h._p(w), w.numel(), h._stream()))
+                                                   h._p(cond), h._p(r0_out), h._p(w), w.numel(), h._stream()))
+
+    # pass A folded into the marching explicit kernel: dot products of R0 with fixed weights (uniform lines), the rest
+    # condensed from the stored R0 (include/adi_hip.h, adi_axis0_dots_*)
+    def dots_supported(self, nxl, ny, nz, sx):
+        return bool(self.lib.adi_axis0_dots_supported(nxl, ny, nz, sx))
+
+    def dots_setup(self, Li, flags_int, dmask_int, theta, gam):
+        """once per (dt, mask): weights, line classes, partial-sum buffer"""
+        h = self.hip
+        pb, lb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self.check(self.lib.adi_axis0_dots_workspace(Li.nx, Li.ny, Li.nz, ctypes.byref(pb), ctypes.byref(lb)))
+        dd = dict(weights=self.vec(Li.nx), part=self.vec(pb.value // 8),
+                  cls=torch.empty(Li.ny * Li.nz, dtype=torch.uint8, device=self.device),
+                  list=torch.empty(lb.value // 4, dtype=torch.int32, device=self.device))
+        self.check(self.lib.adi_axis0_dots_setup(Li.nx, theta, gam, h._p(dd['weights']), h._stream()))
+        self.check(self.lib.adi_axis0_classify(h._p(flags_int), h._p(dmask_int), Li.nx, Li.ny, Li.nz, Li.sx,
+                                               h._p(dd['cls']), h._p(dd['list']), h._stream()))
+        return dd
+
+    def explicit_dots(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin, i_end, dd):
+        h = self.hip
+        self.check(self.lib.adi_explicit_rhs_dots(h._p(T_ext), h._p(flags_ext), L.nx, L.ny, L.nz, L.sx, dx, dt, kappa,
+                                                  theta, h._p(out_ext), i_begin, i_end, h._p(dd['weights']),
+                                                  h._p(dd['part']), h._stream()))
+
+    def dots_finish(self, variant, Li, dd, r0, flags, pack, theta, gam, dt, Tinf, line_begin, line_end, cond):
+        h = self.hip
+        self.check(self.lib.adi_axis0_dots_finish(variant, h._p(dd['part']), h._p(dd['weights']), h._p(dd['cls']),
+                                                  h._p(dd['list']), h._p(r0), h._p(flags), h._p(pack[0]), h._p(pack[1]),
+                                                  h._p(pack[2]), h._p(pack[3]), Li.nx, Li.ny, Li.nz, Li.sx, theta, gam, dt,
+                                                  float(Tinf), line_begin, line_end, h._p(cond), h._stream()))
 
     def interface(self, cond_all, world, rank, nlines, xlo, xhi):
         h = self.hip
@@ -261,6 +293,8 @@ class SlabStepper:
         self._allow_window = True                  # False keeps 'window' plans off (whole-slab condensation only)
         self._allow_fused = True                   # False: explicit stage as its own kernel (R0 through HBM)
         self.fused = False
+        self._keep_r0 = True                       # False: pass B re-evaluates the explicit stage instead of reading R0
+        self._allow_dots = True                    # False: pass A as its own kernel (reads the slab a second time)
         self._comm_stream, self._use_streams = None, False
         self._halo_ready, self._halo_event = None, None
         self._gam = 0.0
@@ -328,7 +362,11 @@ class SlabStepper:
         frac = 0.0
         if self.world > 1:
             frac = 1.0 if (self._a0 is None or self._a0['mode'] != 'window') else min(1.0, 2.0 * self._a0['K'] / self.nxl)
+            if self._a0 is not None and self._a0.get('dots'):
+                frac = 0.0                                  # pass A rides on the explicit stage: no second read
         if self._fused_now():
+            if self._a0 is not None and self._a0.get('keep_r0'):
+                return [2.0 * bpc[0], bpc[1], bpc[2]]      # pass A: state + flags in, R0 out; pass B: R0 + flags in, U out
             return [bpc[0] + frac * (bpc[0] - 8), bpc[1], bpc[2]]
         return [self._explicit_bpc, bpc[0] + frac * (bpc[0] - 8), bpc[1], bpc[2]]
 
@@ -404,7 +442,7 @@ class SlabStepper:
         'slab' (the whole slab is its own window).  Collective: every rank calls it at the same step."""
         prm = self.params
         key = (float(prm.dt), float(prm.theta), self._mask_version, self._force_exact, self._no_overlap,
-               self._allow_fused, self._allow_window)
+               self._allow_fused, self._allow_window, self._keep_r0, self._allow_dots)
         if self._a0_key == key:
             return self._a0
         E, v = self.engine, self.variant
@@ -466,6 +504,19 @@ class SlabStepper:
             flag.fill_(1.0 if plan['fused'] else 0.0)
             self.comm.all_gather(allf, flag)
             plan['fused'] = bool(float(allf.min()) >= 1.0)
+        # whole-slab pass A ('slab', 'exact'): it stores R0 and pass B is the plain sweep; 'window' condenses only the
+        # boundary planes, so its pass B evaluates the explicit stage itself
+        plan['keep_r0'] = bool(plan['fused'] and plan['mode'] != 'window' and self._keep_r0)
+        # whole-slab pass A without a second read of the slab: the marching explicit kernel accumulates the dot products
+        # pass A needs while it writes R0 (uniform lines; the others are condensed from R0); pass B is the plain sweep
+        dots = bool(self._allow_dots and plan['mode'] != 'window' and hasattr(E, 'dots_setup')
+                    and E.dots_supported(self.nxl, self.ny, self.nz, self.Lint.sx))
+        flag.fill_(1.0 if dots else 0.0)
+        self.comm.all_gather(allf, flag)
+        plan['dots'] = bool(float(allf.min()) >= 1.0)
+        if plan['dots']:
+            plan['fused'] = plan['keep_r0'] = False
+            plan['dd'] = E.dots_setup(self.Lint, self.flags_int, self.packs_int[0][1], prm.theta, gam)
         self._a0_key, self._a0 = key, plan
         self.axis0_mode = plan['mode']
         return plan
@@ -477,7 +528,9 @@ class SlabStepper:
         cut = lambda t: None if t is None else t[p0:p1, j0:j1, :]
         fl, pk = cut(self.flags_int), tuple(cut(t) for t in self.packs_int[0])
         if plan['fused']:
-            E.condense0_fused(v, L, src, 1 + p0, j0, fl, pk, self.dx, prm.dt, self._kappa, prm.theta, self.Tinf, cond)
+            # a pass A over the whole slab leaves R0 in the scratch field for pass B (no second explicit evaluation)
+            r0 = _interior(self._tmp[0])[p0:p1, j0:j1, :] if plan['keep_r0'] else None
+            E.condense0_fused(v, L, src, 1 + p0, j0, fl, pk, self.dx, prm.dt, self._kappa, prm.theta, self.Tinf, cond, r0)
         else:
             E.condense(0, v, L, cut(src), fl, pk, prm.theta, self._gam, prm.dt, self.Tinf, cond)
 
@@ -485,6 +538,11 @@ class SlabStepper:
         """pass A on one chunk of lines: the condensations this rank's neighbours need"""
         K, n = plan['K'], self.nxl
         j0, j1 = b['j0'], b['j1']
+        if plan['dots']:
+            E, prm = self.engine, self.params
+            E.dots_finish(self.variant, self.Lint, plan['dd'], Ai, self.flags_int, self.packs_int[0], prm.theta, self._gam,
+                          prm.dt, self.Tinf, j0 * self.nz, j1 * self.nz, b['cond'] if plan['mode'] == 'exact' else b['cond_hi'])
+            return
         if plan['mode'] == 'exact':
             self._condense_box(plan, b['Lb'], Ai, 0, n, j0, j1, b['cond'])
         elif plan['mode'] == 'slab':
@@ -515,7 +573,10 @@ class SlabStepper:
             E.interface_pair(b['cond_lo'], b['cond_hi'], b['prev_hi'] if self.rank > 0 else None,
                              b['next_lo'] if self.rank < self.world - 1 else None, b['nl'], b['xlo'], b['xhi'])
         cut = lambda t: None if t is None else t[:, j0:j1, :]
-        if plan['fused']:
+        if plan['fused'] and plan['keep_r0']:
+            E.sweep(0, v, b['Lb'], cut(_interior(self._tmp[0])), cut(fl), tuple(cut(t) for t in pk), prm.theta, self._gam,
+                    prm.dt, self.Tinf, cut(Bi), b['xlo'], b['xhi'])
+        elif plan['fused']:
             E.sweep0_fused(v, b['Lb'], Ai, 1, j0, cut(fl), tuple(cut(t) for t in pk), self.dx, prm.dt, self._kappa,
                            prm.theta, self.Tinf, cut(Bi), b['xlo'], b['xhi'])
         else:
@@ -636,6 +697,14 @@ class SlabStepper:
             ex(1, nl + 1)
             mark()
             E.sweep(0, v, Li, Ai, fl, self.packs_int[0], prm.theta, gam, prm.dt, self.Tinf, Bi)
+        elif plan['dots']:
+            # one pass over the slab: R0 and, per line, the two dot products of pass A (halos must have landed)
+            if halo_ev is not None and streams:
+                main.wait_event(halo_ev)
+            E.explicit_dots(self.Lext, Text, self.flags_ext, self.dx, prm.dt, kappa, prm.theta, A, 1, nl + 1, plan['dd'])
+            mark()
+            ev_x = self._axis0_pipeline(plan, Ai, Bi)
+            self._axis0_finish(plan, Ai, Bi, ev_x)
         elif plan['mode'] == 'window':
             # the boundary windows first: their condensation travels while the middle planes are computed
             K = plan['K']
@@ -673,7 +742,7 @@ class SlabStepper:
                                      tuple(None if t is None else t[p0:p1] for t in pk2), prm.theta, gam, prm.dt,
                                      self.Tinf, Oi[p0:p1])
         # the fused passes and the 'window' form start with planes that need the halos: send them early
-        if prefetch_halo and self.world > 1 and nl >= 4 and (plan['mode'] == 'window' or fused):
+        if prefetch_halo and self.world > 1 and nl >= 4 and (plan['mode'] == 'window' or fused or plan['dots']):
             sw2(0, 1); sw2(nl - 1, nl)                        # the two planes the neighbours need
             if streams:
                 ev0 = torch.cuda.Event(); ev0.record(main)

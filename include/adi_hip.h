@@ -149,6 +149,8 @@ int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t 
  * allocation (whole buffer: valid_lo = -(offset of d_T in it), valid_hi = its length - that offset).
  * adi_explicit_fused_supported(pass): 1 when pass 0 (sweep) / pass 1 (condensation) can run fused on this box
  * (nx <= 1024 planes; pass 1: whole register segments); otherwise run adi_explicit_rhs + adi_sweep.
+ * adi_explicit_condense0: d_R0_out (optional, same box layout as d_T) also receives R0, so that pass B can be the plain
+ * adi_sweep on it instead of evaluating the explicit stage a second time.
  */
 int adi_explicit_fused_supported(int nx, int ny, int nz, long plane_stride, int pass);
 int adi_explicit_sweep0(int variant, const double *d_T, long valid_lo, long valid_hi, const uint8_t *d_flags,
@@ -161,7 +163,31 @@ int adi_explicit_condense0(int variant, const double *d_T, long valid_lo, long v
                            const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
                            const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse,
                            double dx, double dt, double kappa, double theta, double Tinf,
-                           double *d_cond, void *d_work, size_t work_bytes, void *stream);
+                           double *d_cond, double *d_R0_out, void *d_work, size_t work_bytes, void *stream);
+/*
+ * Pass A folded into the explicit stage (ABI v7): for a line whose rows are uniform along axis 0 (solid interior; at
+ * most one end row differs) the six pass-A numbers follow from two dot products of R0 with fixed weights -- the first
+ * column u of tridiag(-tg, 1+2tg, -tg)^-1 and its reverse -- which the marching explicit kernel accumulates while it
+ * writes R0, so the slab's inputs are read once.  Lines that are not uniform are condensed from the stored R0.
+ *   adi_axis0_dots_setup      u for (n, theta, gam) -> d_weights[n]                       (once per dt; synchronises)
+ *   adi_axis0_classify        d_cls[ny*nz] (1 = uniform) and d_list (count + ids of the others)   (once per mask)
+ *   adi_explicit_rhs_dots     adi_explicit_rhs_planes + partial dot products d_part (adi_axis0_dots_workspace)
+ *   adi_axis0_dots_finish     -> d_cond [6][line_end - line_begin] of the lines [line_begin, line_end), the format of
+ *                             adi_sweep_condense; arrays are those of the box (nx = i_end - i_begin planes)
+ */
+int adi_axis0_dots_supported(int nx, int ny, int nz, long plane_stride);
+int adi_axis0_dots_workspace(int nx, int ny, int nz, size_t *part_bytes, size_t *list_bytes);
+int adi_axis0_dots_setup(int n, double theta, double gam, double *d_weights, void *stream);
+int adi_axis0_classify(const uint8_t *d_flags, const uint8_t *d_dir_mask, int nx, int ny, int nz, long plane_stride,
+                       uint8_t *d_cls, unsigned *d_list, void *stream);
+int adi_explicit_rhs_dots(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride,
+                          double dx, double dt, double kappa, double theta, double *d_R0, int i_begin, int i_end,
+                          const double *d_weights, double *d_part, void *stream);
+int adi_axis0_dots_finish(int variant, const double *d_part, const double *d_weights, const uint8_t *d_cls,
+                          const unsigned *d_list, const double *d_R0, const uint8_t *d_flags, const double *d_coeff,
+                          const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux,
+                          int nx, int ny, int nz, long plane_stride, double theta, double gam, double dt, double Tinf,
+                          long line_begin, long line_end, double *d_cond, void *stream);
 /* d_cond_all: [nranks][6][nlines], the all-gathered pass-A output ordered by slab.  Solves the reduced
  * interface system of every line and writes this rank's boundary values for pass B (adi_sweep). */
 int adi_interface_solve(const double *d_cond_all, int nranks, int rank, long nlines,

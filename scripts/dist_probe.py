@@ -41,10 +41,12 @@ def main():
     st._force_exact = bool(int(os.environ.get('PROBE_EXACT', '0')))
     pre = bool(int(os.environ.get('PROBE_PREFETCH', '1')))
     st._allow_fused = bool(int(os.environ.get('PROBE_FUSED', '1')))
+    st._keep_r0 = bool(int(os.environ.get('PROBE_KEEP_R0', '1')))
+    st._allow_dots = bool(int(os.environ.get('PROBE_DOTS', '1')))
     for _ in range(3):
         T = st.step(T, prefetch_halo=pre)
     torch.cuda.synchronize()
-    print('axis-0 interface form:', st.axis0_mode, 'K =', st._a0['K'], 'chunks =', len(st._a0['chunks']), 'fused =', st._a0['fused'])
+    print('axis-0 interface form:', st.axis0_mode, 'K =', st._a0['K'], 'chunks =', len(st._a0['chunks']), 'fused =', st._a0['fused'], 'dots =', st._a0['dots'])
     K = 10
     nst = len(st.stage_names)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(K)]

@@ -121,9 +121,29 @@ class CpuEngine:
         self.sweep(0, variant, L, r0, flags, pack, theta, kappa * dt / (dx * dx), dt, Tinf, tmp, xlo, xhi)
         t_out.copy_(tmp)
 
-    def condense0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, cond):
+    def condense0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, cond, r0_out=None):
         r0 = self._r0_box(L, T_ext, i0, j0, flags, dx, dt, kappa, theta)
+        if r0_out is not None:
+            r0_out.copy_(r0)
         self.condense(0, variant, L, r0, flags, pack, theta, kappa * dt / (dx * dx), dt, Tinf, cond)
+
+    # pass A folded into the explicit stage (product: dot products in the marching kernel): here the explicit stage
+    # followed by the dense condensation of the requested lines
+    def dots_supported(self, nxl, ny, nz, sx):
+        return True
+
+    def dots_setup(self, Li, flags_int, dmask_int, theta, gam):
+        return {}
+
+    def explicit_dots(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin, i_end, dd):
+        self.explicit(L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin, i_end)
+
+    def dots_finish(self, variant, Li, dd, r0, flags, pack, theta, gam, dt, Tinf, line_begin, line_end, cond):
+        j0, j1 = line_begin // Li.nz, line_end // Li.nz
+        assert j0 * Li.nz == line_begin and j1 * Li.nz == line_end
+        cut = lambda t: None if t is None else t[:, j0:j1, :]
+        self.condense(0, variant, CpuLayout(Li.nx, j1 - j0, Li.nz), cut(r0), cut(flags), tuple(cut(t) for t in pack), theta,
+                      gam, dt, Tinf, cond)
 
     def sweep(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, xlo=None, xhi=None):
         a, b, c, d = _line_systems(axis, t_in, flags, pack, theta, gam, dt, Tinf)

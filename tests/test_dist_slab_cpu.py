@@ -61,6 +61,8 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q, opts=None):
         st._force_exact = bool(opts.get('force_exact', False))
         st._allow_window = bool(opts.get('allow_window', True))
         st._allow_fused = bool(opts.get('allow_fused', True))
+        st._keep_r0 = bool(opts.get('keep_r0', True))
+        st._allow_dots = bool(opts.get('allow_dots', True))
         T = torch.from_numpy(np.ascontiguousarray(c['T0'][i0:i1]))
         for s in range(nsteps):
             T = st.step(T, prefetch_halo=bool(opts.get('prefetch', False)) and s + 1 < nsteps)
@@ -84,7 +86,7 @@ def test_slab_decomposition_matches_single_domain(world, case_name, fused):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case_name, sizes, nsteps, q, dict(allow_fused=fused)))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case_name, sizes, nsteps, q, dict(allow_fused=fused, allow_dots=not fused)))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -121,6 +123,9 @@ def _run_world(world, case_name, sizes, nsteps, opts):
     (2, 128, dict(force_exact=True, prefetch=True), 'exact'),
     (2, 128, dict(prefetch=True, allow_fused=False), 'window'),
     (3, 72, dict(prefetch=True, allow_fused=False), 'slab'),
+    (3, 72, dict(prefetch=True, keep_r0=False, allow_dots=False), 'slab'),
+    (3, 72, dict(prefetch=True, allow_dots=False), 'slab'),
+    (2, 128, dict(force_exact=True, prefetch=True, allow_dots=False), 'exact'),
 ])
 def test_neighbour_only_interface_matches_single_domain(world, nx, opts, mode):
     """thick slabs / small dt: the reduced system splits into 2x2 neighbour systems (dist_slab docstring); the result

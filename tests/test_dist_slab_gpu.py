@@ -35,6 +35,9 @@ def _run_slabs(c, world, sizes, nsteps, opts=None, modes=None):
             o = opts or {}
             st._force_exact = bool(o.get('force_exact', False))
             st._allow_window = bool(o.get('allow_window', True))
+            st._allow_fused = bool(o.get('allow_fused', True))
+            st._allow_dots = bool(o.get('allow_dots', True))
+            st._keep_r0 = bool(o.get('keep_r0', True))
             T = hip.to_device(np.ascontiguousarray(c['T0'][i0:i1]))
             for s in range(nsteps):
                 T = st.step(T, prefetch_halo=bool(o.get('prefetch', False)) and s + 1 < nsteps)
@@ -55,9 +58,18 @@ def _run_slabs(c, world, sizes, nsteps, opts=None, modes=None):
     return np.concatenate(out, axis=0)
 
 
-@pytest.mark.parametrize('world,case_name', [(2, 'holes_mixed'), (3, 'kat2'), (4, 'long_line_70'), (3, 'slab_chunks'),
-                                             (2, 'dirichlet_only_gamma07')])
-def test_slabs_match_single_domain(world, case_name):
+# pass-A forms: dot products inside the explicit stage (default), fused strided pass A (with / without R0 kept for
+# pass B), explicit stage + pass A as separate kernels
+PASS_A = {'dots': {}, 'fused': dict(allow_dots=False), 'fused_recompute': dict(allow_dots=False, keep_r0=False),
+          'separate': dict(allow_dots=False, allow_fused=False)}
+
+
+@pytest.mark.parametrize('world,case_name,form', [(2, 'holes_mixed', 'dots'), (2, 'holes_mixed', 'fused'),
+                                                  (2, 'holes_mixed', 'separate'), (3, 'kat2', 'dots'),
+                                                  (3, 'kat2', 'fused_recompute'), (4, 'long_line_70', 'dots'),
+                                                  (4, 'long_line_70', 'fused'), (3, 'slab_chunks', 'dots'),
+                                                  (3, 'slab_chunks', 'separate'), (2, 'dirichlet_only_gamma07', 'dots')])
+def test_slabs_match_single_domain(world, case_name, form):
     from oracle import adi_oracle as orc
     from adi_thermal_fields_amd.dist_slab import split_planes
     c = cases.cart_case(case_name)
@@ -66,7 +78,7 @@ def test_slabs_match_single_domain(world, case_name):
     base = nx // world
     sizes = [base] * world
     sizes[-1] += nx - base * world            # ragged / odd sizes -> generic condensation kernel
-    got = _run_slabs(c, world, sizes, nsteps)
+    got = _run_slabs(c, world, sizes, nsteps, PASS_A[form])
     c2 = dict(c); c2['nsteps'] = nsteps
     want = run_cart_case(orc, c2)['T_final']
     assert rel_linf(got, want) <= 1e-10, rel_linf(got, want)
@@ -83,14 +95,18 @@ def test_slabs_even_sizes_fast_condense_512_lines():
     c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,
              T0=rng.uniform(20.0, 1200.0, shape), dir_mask=None, dir_value=None, neumann={'x-': 4e5},
              robin_h=350.0, Tinf=20.0, theta=0.5, dt=300.0 * dx * dx / alpha, nsteps=2, births=None)
-    got = _run_slabs(c, 4, [64, 64, 64, 64], 2)
     want = run_cart_case(hip, c)['T_final']
-    assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
+    for form, o in PASS_A.items():
+        got = _run_slabs(c, 4, [64, 64, 64, 64], 2, o)
+        assert rel_linf(got, want) <= 1e-12, (form, rel_linf(got, want))
 
 
 @pytest.mark.parametrize('cfl,opts,mode', [(0.1, dict(prefetch=True), 'window'), (3.0, dict(prefetch=True), 'slab'),
                                            (0.1, dict(allow_window=False), 'slab'), (300.0, dict(prefetch=True), 'exact'),
-                                           (0.1, dict(force_exact=True), 'exact')])
+                                           (0.1, dict(force_exact=True), 'exact'),
+                                           (3.0, dict(prefetch=True, allow_dots=False), 'slab'),
+                                           (300.0, dict(prefetch=True, allow_dots=False), 'exact'),
+                                           (3.0, dict(prefetch=True, allow_dots=False, allow_fused=False), 'slab')])
 def test_slabs_interface_forms_agree(cfl, opts, mode):
     """4 slabs of 64 planes: neighbour-only interface solve on 16-plane windows (cfl 0.1), on whole slabs (cfl 3),
     all-gather solve (cfl 300: no decay) -- each against the single-domain HIP step"""
@@ -125,3 +141,22 @@ def test_slabs_window_solid_512_lines():
     assert modes == {'window'}, modes
     want = run_cart_case(hip, c)['T_final']
     assert rel_linf(got, want) <= 1e-13, rel_linf(got, want)
+
+
+def test_slabs_solid_512_lines_dots_all_ranks():
+    """all-solid grid, Robin + a Neumann face on the global axis-0 ends: every line is uniform, the first and last
+    rank's lines carry the modified end row (Sherman-Morrison branch of k_dots_finish), the middle rank none"""
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    rng = np.random.default_rng(9)
+    shape = (384, 8, 32)
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=np.ones(shape, bool),
+             T0=rng.uniform(20.0, 1200.0, shape), dir_mask=None, dir_value=None, neumann={'x-': 3e5, 'x+': 1e5},
+             robin_h=rng.uniform(100.0, 600.0, shape), Tinf=20.0, theta=0.5, dt=150.0 * dx * dx / alpha, nsteps=2,
+             births=None)
+    want = run_cart_case(hip, c)['T_final']
+    for o in (dict(prefetch=True), dict(force_exact=True)):
+        modes = set()
+        got = _run_slabs(c, 3, [128, 128, 128], 2, o, modes)
+        assert rel_linf(got, want) <= 1e-12, (o, modes, rel_linf(got, want))
