@@ -36,7 +36,7 @@ import threading
 import numpy as np
 import torch
 
-__all__ = ['SlabStepper', 'TorchDistComm', 'LocalComm', 'HipEngine', 'split_planes']
+__all__ = ['SlabStepper', 'TorchDistComm', 'LocalComm', 'LoopbackComm', 'HipEngine', 'split_planes']
 
 
 def split_planes(nx, world):
@@ -124,6 +124,24 @@ class LocalComm:
         for r in range(self.world):
             flat[r * n:(r + 1) * n].copy_(self.sh.slots[('ag', r)].view(-1))
         self._sync()
+
+
+class LoopbackComm:
+    """Rehearsal on ONE GPU: this rank talks to copies of itself, so a step executes every kernel and host call a
+    rank of a `world`-GPU run executes, with no wire time (scripts/dist_probe.py, bench.py --rehearse-world).
+    Not a product path."""
+
+    def __init__(self, world, rank):
+        self.world, self.rank = world, rank
+
+    def exchange_planes(self, send_lo, send_hi, recv_lo, recv_hi):
+        if self.rank > 0:
+            recv_lo.copy_(send_hi)          # what a copy of this rank sitting below would send up
+        if self.rank < self.world - 1:
+            recv_hi.copy_(send_lo)
+
+    def all_gather(self, out, inp):
+        out.view(self.world, -1).copy_(inp.view(1, -1).expand(self.world, -1))
 
 
 # ------------------------------------------------------------------------------------------ engine

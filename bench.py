@@ -38,6 +38,9 @@ def parse():
     ap.add_argument('--n', type=int, default=512, help='cells per axis per GPU')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-n', type=int, default=256, help='edge of the bounded CPU-baseline sample')
+    ap.add_argument('--rehearse-world', type=int, default=0,
+                    help='one GPU only: run the code path of a middle rank of a W-GPU job with a loopback communicator '
+                         '(no wire time); the line is marked "rehearsal" and is not a measurement of W GPUs')
     return ap.parse_args()
 
 
@@ -72,6 +75,8 @@ def main():
     a = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    rehearse = a.rehearse_world if (a.rehearse_world > 1 and world == 1 and a.gpus == 1) else 0
+    multi = world > 1 or rehearse > 1          # the slab code path
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if a.gpus > 1 and world == 1:
         print('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % a.gpus,
@@ -98,7 +103,7 @@ def main():
     T0 = torch.rand((n, n, n), dtype=torch.float64, device=dev, generator=gen) * 980.0 + 20.0
 
     stage_names = ['explicit', 'sweep_axis0', 'sweep_axis1', 'sweep_axis2_contig']
-    if world == 1:
+    if world == 1 and not rehearse:
         grid = adi.Grid3D(n, n, n, dx, np.ones((n, n, n), bool))
         packs = adi.precompute_coeff_packs_unified(grid, mat, robin_h=500.0)
         T = adi.DeviceField(T0)
@@ -107,11 +112,11 @@ def main():
         variant = packs[0].variant
     else:
         from adi_thermal_fields_amd import dist_slab
+        comm = dist_slab.LoopbackComm(rehearse, rehearse // 2) if rehearse else None
         stepper = dist_slab.SlabStepper.from_local(T0, np.ones((n, n, n), bool), dx, mat, prm, Tinf,
-                                                   robin_h=500.0)
+                                                   robin_h=500.0, comm=comm)
         T = adi.DeviceField(T0)
         variant = stepper.variant
-        stage_names = stepper.stage_names
         overlap_err, overlap_on = stepper.self_check(T)     # pipeline on the second stream vs plain ordering
 
     def sync():
@@ -119,9 +124,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kw = dict(prefetch_halo=True) if world > 1 else {}     # the loop feeds every step's output to the next unmodified
+    kw = dict(prefetch_halo=True) if multi else {}     # the loop feeds every step's output to the next unmodified
     for _ in range(a.warmup):
         T = stepper.step(T, **kw)
+    if multi:
+        if a.warmup == 0:
+            T = stepper.step(T, **kw)                      # the plan (and with it the stage list) exists after one step
+        stage_names = stepper.stage_names                  # depends on the axis-0 plan chosen for this dt / mask
     nst = len(stage_names)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(a.steps)]
     sync()
@@ -154,7 +163,7 @@ def main():
     # general-pack (42 B/cell) contiguous-axis sweep: the kernel the 60 % target is written against; measured
     # outside the timed region of the step loop with the same event method
     xs = None
-    if world == 1:
+    if not multi:
         # The same three sweeps with every pack array read in full (42 B/cell, the reference's own data model,
         # SURVEY.md 8(d)), measured outside the timed region with the same event method.  The contiguous one is
         # the kernel the 60 % target of BASELINE.json is written against.
@@ -191,19 +200,24 @@ def main():
         dtype='f64', data='synthetic',
         config=dict(workload='%dx%dx%d fp64 Cartesian, Robin h=500 all faces, theta=0.5, cfl=200, all-solid mask'
                              % (world * n, n, n),
-                    cells_per_gpu=N, decomposition=('none' if world == 1 else 'slabs along memory axis 0'),
+                    cells_per_gpu=N, decomposition=('slabs along memory axis 0' if multi else 'none'),
                     sweep_variant={0: 'general', 1: 'no_dir', 2: 'no_q', 3: 'lean'}[variant]),
         cell_updates_per_s=round(world * N * a.steps / elapsed, 1),
         step_achieved_gbs=round(sum(bytes_per_cell.values()) * N / (ms_per_step * 1e-3) / 1e9, 1),
         **({'comm_overlap': dict(enabled=overlap_on, selfcheck_rel_diff=overlap_err,
-                                 axis0_interface=stepper.axis0_mode)} if world > 1 else {}),
+                                 axis0_interface=stepper.axis0_mode,
+                                 pass_a=('dots_in_explicit' if stepper._a0.get('dots') else
+                                         ('fused' if stepper._a0.get('fused') else 'separate')))} if multi else {}),
+        **({'rehearsal': 'ONE GPU running the code path of rank %d of %d with a loopback communicator: per-rank compute '
+                         'time without wire time, not a %d-GPU measurement' % (rehearse // 2, rehearse, rehearse)}
+           if rehearse else {}),
         roofline=dict(bound='hbm', kernel=dom, achieved=kernels[dom]['achieved_gbs'], peak=HBM_PEAK_GBS,
                       unit='GB/s', frac=kernels[dom]['frac'], traffic=traffic),
         kernels=kernels,
     )
     if xs is not None:
         line['general_pack_sweeps_42B'] = xs
-    if world == 1 and not a.no_cpu:
+    if world == 1 and not rehearse and not a.no_cpu:
         st, mt = cpu_baseline(a.cpu_n)
         line['cpu_baseline'] = st
         line['cpu_baseline_all_cores'] = mt
