@@ -72,3 +72,37 @@ def test_512_properties():
     # 4. maximum principle: the step cannot leave the range spanned by the field and the ambient
     o = step(T1, 20.0)
     assert float(o.max()) <= float(T1.max()) + 1e-9 and float(o.min()) >= 20.0 - 1e-9
+
+
+def _config4(nphi):
+    """BASELINE.json configs[3] / SURVEY.md 8(d) config 4: cylindrical 128 x 256 x 512, dr = dz = 2.5e-4, BE, dt = 0.05,
+    T0 = 20 with the top 16 z-planes at 1000 (birth-like), Robin wall h = 400, z: neumann0 / robin h = 500"""
+    nr, nz = 128, 512
+    T0 = np.full((nr, nphi, nz), 20.0)
+    T0[:, :, -16:] = 1000.0
+    return dict(shape=(nr, nphi, nz), dr=2.5e-4, dz=2.5e-4, dphi=2.0 * np.pi / 256, R=0.032,
+                mat=dict(STEEL), T0=T0, robin_r=(400.0, 20.0),
+                zbc=dict(kind_bot='neumann0', kind_top='robin', h_top=500.0, T_inf_top=20.0), dt=0.05, S=None,
+                active=None)
+
+
+def test_config4_cylindrical_128x256x512():
+    """(1) 3 steps on the full grid against the NumPy oracle directly (rel L-inf <= 1e-10);
+    (2) all 50 steps on the full grid against the oracle run on ONE phi column: T0 and the BCs do not depend on phi,
+    the phi solve of a phi-constant field returns it, so the 3-D solution is that column replicated -- a
+    size-independent property that lets the 16.7M-cell, 50-step run be checked in seconds (the oracle takes 16 s per
+    full-size step)."""
+    import adi_thermal_fields_amd.adi3d_hip_cyl as hipcyl
+    from oracle import cyl_oracle as cyl
+    from helpers import run_cyl_case
+    c = _config4(256)
+    c3 = dict(c, nsteps=3)
+    got3 = run_cyl_case(hipcyl, c3)['T_final']
+    want3 = run_cyl_case(cyl, c3)['T_final']
+    assert rel_linf(got3, want3) <= 1e-10, rel_linf(got3, want3)
+    del want3
+    got = run_cyl_case(hipcyl, dict(c, nsteps=50))['T_final']
+    col = run_cyl_case(cyl, dict(_config4(1), nsteps=50))['T_final']          # (128, 1, 512)
+    assert rel_linf(got, np.broadcast_to(col, got.shape)) <= 1e-10, rel_linf(got, np.broadcast_to(col, got.shape))
+    assert float(np.abs(got - got[:, :1, :]).max()) <= 1e-9                     # still phi-independent
+    assert 20.0 - 1e-9 <= got.min() and got.max() <= 1000.0 + 1e-9              # maximum principle
