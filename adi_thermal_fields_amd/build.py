@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libadi_hip.so')
-SOURCES = ['adi_cart.hip', 'adi_cyl.hip', 'adi_ctx.hip']
+SOURCES = ['adi_cart.hip', 'adi_cyl.hip', 'adi_ctx.hip', 'adi_morph.hip']
 HEADERS = ['adi_core.hpp', 'adi_common.hpp', os.path.join('..', '..', 'include', 'adi_hip.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fno-fast-math', '-Wall',

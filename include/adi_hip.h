@@ -211,6 +211,20 @@ int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_t
              int nx, int ny, int nz, long plane_stride, double dx, double rho, double cp, double k,
              double dt, double theta, double Tinf, void *d_work, size_t work_bytes, void *stream);
 
+/*
+ * The callers either side of the path.  Masks here are DENSE uint8 (nx, ny, nz), C order.
+ * adi_morph6: op 0 = dilate6 (waam_from_stl_v7_mm.py:73-82), op 1 = erode6 (:84-96); d_out must not alias d_in.
+ * adi_flood_outside: flood_fill_outside (:106-134) as its comment describes it -- air connected to the outside of the
+ *   box through 6-connectivity (the reference pads the solid with True and therefore returns all-False: DESIGN.md D8);
+ *   line scans instead of one-cell dilations; d_flag: one int of device scratch; synchronises the stream.
+ * adi_pack_frame_f32be: fp64 field in the padded-plane layout -> big-endian float32 in VTK point order (x fastest),
+ *   the payload of a legacy-VTK BINARY SCALARS block (the reference writes ASCII: vtk_writer.py:4-30).
+ */
+int adi_morph6(int op, const uint8_t *d_in, uint8_t *d_out, int nx, int ny, int nz, void *stream);
+int adi_flood_outside(const uint8_t *d_solid, uint8_t *d_outside, int nx, int ny, int nz, int *d_flag, int *rounds,
+                      void *stream);
+int adi_pack_frame_f32be(const double *d_T, int nx, int ny, int nz, long plane_stride, uint32_t *d_out, void *stream);
+
 /* T[sel != 0] = value   (layer birth: waam_from_stl_v7_mm.py:487-495 `T[newborn] = Ts`); flat over n elements */
 int adi_masked_fill(double *d_T, const uint8_t *d_sel, size_t n, double value, void *stream);
 /* dst = a | b  (birth bookkeeping: mask_act |= newborn) */
