@@ -570,6 +570,59 @@ class StagedStepper:
         _sweep_into(axis, t_in, t_out, self.grid, self.mat, self.params, self.packs[axis], self.Tinf, variant,
                     dense=dense)
 
+    def _step_into(self, t, out):
+        """one step t -> out (both native-layout device tensors), no allocation: what a HIP graph captures"""
+        g, prm = self.grid, self.params
+        (ta, tb), _, _ = g.scratch(2)
+        kappa, _ = _gam(g, self.mat, prm)
+        if self.fused:
+            _explicit_sweep0_into(t, tb, g, self.mat, prm, self.packs[0], self.Tinf)
+        else:
+            check(lib.adi_explicit_rhs(_p(t), _p(g.d_flags), g.nx, g.ny, g.nz, g.sx, g.dx, prm.dt, kappa, prm.theta,
+                                       _p(ta), _stream()))
+            self.sweep_into(0, ta, tb)
+        self.sweep_into(1, tb, ta)
+        self.sweep_into(2, ta, out)
+
+    def run(self, T, nsteps, graph=True):
+        """The drivers' `nsub` loop (quick_compare_dirichlet_robin.py:169-178, waam_from_stl_v7_mm.py:525-528): `nsteps`
+        steps with the same packs and dt on a device-resident field, returned as a new DeviceField.  The launches of
+        two steps (X -> Y -> X) are captured once into a HIP graph and replayed, so small grids are not bound by the
+        host's launch path (64^3: 3 kernels + 3 memsets per step, each a ctypes call); the graph is rebuilt when dt,
+        theta, Tinf, the mask or the packs change.  graph=False: plain launches."""
+        g, prm = self.grid, self.params
+        nsteps = int(nsteps)
+        key = (float(prm.dt), float(prm.theta), self.Tinf, g.mask_version, tuple(id(p) for p in self.packs),
+               tuple(None if p.d_coeff is None else p.d_coeff.data_ptr() for p in self.packs), self.fused)
+        st = getattr(self, '_graph', None)
+        if st is None or st['key'] != key:
+            X, Y = g.layout.empty(), g.layout.empty()
+            st = self._graph = dict(key=key, X=X, Y=Y, g=None)
+        X, Y = st['X'], st['Y']
+        X.copy_(g.layout.to_layout(T, torch.float64))
+        if graph and nsteps >= 2 and st['g'] is None:
+            g.scratch(2)                                   # every buffer exists before the capture
+            self._step_into(X, Y); self._step_into(Y, X)   # warm-up outside the capture (lazy module loads); harmless:
+            X.copy_(g.layout.to_layout(T, torch.float64))  # X is restored
+            torch.cuda.synchronize()
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                self._step_into(X, Y)
+                self._step_into(Y, X)
+            st['g'] = cg
+        done = 0
+        if graph and st['g'] is not None:
+            for _ in range(nsteps // 2):
+                st['g'].replay()
+            done = 2 * (nsteps // 2)
+        cur, oth = X, Y
+        for _ in range(nsteps - done):
+            self._step_into(cur, oth)
+            cur, oth = oth, cur
+        out = g.layout.empty()
+        out.copy_(cur)
+        return DeviceField(out)
+
     def step(self, T, events=None):
         g, prm = self.grid, self.params
         t = g.layout.to_layout(T, torch.float64)

@@ -66,6 +66,9 @@ def birth_times(mask_full, layers, dx, bead_width, scan_speed, eta_fill=1.0):
     return times
 
 
+GRAPH_MIN_NSUB = 16      # segments at least this long run through StagedStepper.run (graph capture costs about a step)
+
+
 def _is_device_backend(backend):
     return hasattr(backend, 'to_device')
 
@@ -111,8 +114,12 @@ def run_layer_birth(backend, mask_full, dx, mat_args, h, Tinf, Ts, theta, cfl, l
         nonlocal T, nsteps
         nsub = max(1, int(math.ceil(seg / dt_cap)))
         params.dt = max(seg / nsub, 1e-15)
-        for _ in range(nsub):
-            T = _step(backend, T, grid, mat, params, packs, Tinf)
+        if nsub >= GRAPH_MIN_NSUB and hasattr(backend, 'StagedStepper') and hasattr(T, 'fill_where'):
+            # a long segment on the device backend: the nsub launches of this segment replayed from a HIP graph
+            T = backend.StagedStepper(grid, mat, params, packs, Tinf).run(T, nsub)
+        else:
+            for _ in range(nsub):
+                T = _step(backend, T, grid, mat, params, packs, Tinf)
         nsteps += nsub
 
     events = sorted(set(list(times_out) + list(times_birth)))

@@ -279,3 +279,36 @@ def test_fused_explicit_sweep0_is_bit_identical(hip, shape, fill, bc):
     hip._explicit_sweep0_into(view, out, grid, mat, prm, packs[0], 25.0)
     assert np.array_equal(out.cpu().numpy(), one if variant is None else
                           hip.adi_explicit_sweep_axis0(T0, grid, mat, prm, packs[0], Tinf=25.0))
+
+
+@pytest.mark.parametrize('shape,nsteps', [((24, 20, 32), 7), ((64, 64, 64), 10), ((16, 16, 16), 1)])
+def test_graph_replayed_nsub_loop_matches_plain_steps(hip, shape, nsteps):
+    """StagedStepper.run (two steps captured into a HIP graph and replayed) == the same number of plain steps, bit for
+    bit; the graph is rebuilt when dt changes (drivers mutate params.dt between segments) and when the mask changes"""
+    rng = np.random.default_rng(shape[0] + nsteps)
+    mask = rng.random(shape) < 0.9
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    grid = hip.Grid3D(*shape, dx, mask)
+    mat = hip.Material(7800.0, 490.0, 54.0)
+    prm = hip.Params(30.0 * dx * dx / alpha, 0.5)
+    packs = hip.precompute_coeff_packs_unified(grid, mat, robin_h=300.0, neumann={'z-': 1e5})
+    T0 = rng.uniform(20.0, 900.0, shape)
+    st = hip.StagedStepper(grid, mat, prm, packs, Tinf=25.0)
+
+    def plain(T, n):
+        T = hip.to_device(T)
+        for _ in range(n):
+            T = hip.adi_step_hip_coeff(T, grid, mat, prm, packs, Tinf=25.0)
+        return T.get()
+    got = st.run(hip.to_device(T0), nsteps).get()
+    assert np.array_equal(got, plain(T0, nsteps))
+    assert np.array_equal(st.run(T0, nsteps, graph=False).get(), got)
+    prm.dt *= 0.5                                            # new segment: same stepper object, new dt
+    got2 = st.run(hip.to_device(got), nsteps + 1).get()
+    assert np.array_equal(got2, plain(got, nsteps + 1))
+    mask2 = mask.copy(); mask2[:, :, : shape[2] // 2] = True  # birth: mask + packs change
+    grid.mask = mask2
+    packs = hip.precompute_coeff_packs_unified(grid, mat, robin_h=300.0, neumann={'z-': 1e5})
+    st = hip.StagedStepper(grid, mat, prm, packs, Tinf=25.0)
+    assert np.array_equal(st.run(got2, 4).get(), plain(got2, 4))

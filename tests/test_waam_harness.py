@@ -174,3 +174,17 @@ def test_config5_full_256x256x320_4_slabs_match_one_domain():
     assert np.all(want[~mask] == 20.0) and 20.0 < want[mask].max() <= 1000.0 + 1e-9 and want.min() >= 20.0 - 1e-9
     got = _slab_run(4, [64, 64, 64, 64], mask, dx, layers, times, outs, theta)
     assert rel_linf(got, want) <= 1e-11, rel_linf(got, want)
+
+
+@pytest.mark.gpu
+def test_layer_birth_long_segments_use_graph_and_match_oracle():
+    """small cfl -> segments of dozens of sub-steps: the device backend replays them from a HIP graph
+    (StagedStepper.run); same result as the oracle driven through the same loop"""
+    from oracle import adi_oracle as orc
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    waam, mask, layers, dx, times = _setup((16, 16, 20))
+    outs = [0.0, times[-1]]
+    want, n1 = waam.run_layer_birth(orc, mask, dx, STEEL, 40.0, 20.0, 1000.0, 0.5, 0.25, layers, times, outs)
+    got, n2 = waam.run_layer_birth(hip, mask, dx, STEEL, 40.0, 20.0, 1000.0, 0.5, 0.25, layers, times, outs)
+    assert n1 == n2 and n1 / len(layers) >= waam.GRAPH_MIN_NSUB
+    assert rel_linf(got, want) <= 1e-10, rel_linf(got, want)
