@@ -28,6 +28,10 @@
 
 namespace adi {
 
+#ifndef ADI_BUF_STRIDED
+#define ADI_BUF_STRIDED 1   // unfused strided FAST kernels: buffer addressing for whole tiles (0: flat loads)
+#endif
+constexpr bool kBufStrided = ADI_BUF_STRIDED != 0;
 #ifndef ADI_FUSE_D
 #define ADI_FUSE_D 8     // rows of j-neighbour loads in flight per thread in the fused FAST kernels (2: 0.77 ms, 4: 0.70, 8: 0.68 at 512^3)
 #endif
@@ -685,6 +689,55 @@ __device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in_
     return lane_fast;
 }
 
+// Buffer addressing (raw_buffer_load/store: 128-bit descriptor + per-thread 32-bit byte offset + scalar byte offset):
+// a strided tile touches M rows x several arrays, and with flat global loads every one of them costs 64-bit address
+// arithmetic in the VALU (measured: half of the fused kernel's VALU instructions); here the row offsets live in
+// scalar registers and one per-thread offset serves every load.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x)
+{
+    u32x2 v;
+    v.x = (unsigned)__double2loint(x); v.y = (unsigned)__double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+
+// The same for whole tiles (block-uniform precondition: every lane active, every thread owns M rows), buffer
+// addressing: scalar row offsets, one per-thread offset, no per-row predicates and no 64-bit address arithmetic.
+template <int M, bool HAS_DIR>
+__device__ __forceinline__ bool fast_segment_load_buf(const double *__restrict__ in_t, const uint8_t *__restrict__ flags_t,
+                                                      const uint8_t *__restrict__ dmask_t, const LineGeom &g, unsigned voff,
+                                                      double (&d)[M], unsigned &f0, unsigned &fS, bool &dirS)
+{
+    const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void *)in_t, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void *)flags_t, 0, 0x7fffffff, 0x00020000);
+    const unsigned st = (unsigned)g.stride;
+    bool lane_fast = true;
+    f0 = 0; fS = 0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        const unsigned f = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, 0);
+        d[r] = buf_load_f64(rT, voff * 8u, (unsigned)r * st * 8u);
+        if (r == 0) { f0 = f; lane_fast = lane_fast && ((f & ROW0) == ROW0); }
+        else if (r == M - 1) fS = f;
+        else lane_fast = lane_fast && ((f & FULL) == FULL);
+    }
+    dirS = false;
+    if (HAS_DIR) {
+        const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void *)dmask_t, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < M - 1; ++r)
+            lane_fast = lane_fast && (__builtin_amdgcn_raw_buffer_load_b8(rD, voff, (unsigned)r * st, 0) == 0);
+        dirS = __builtin_amdgcn_raw_buffer_load_b8(rD, voff, (unsigned)(M - 1) * st, 0) != 0;
+    }
+    return lane_fast;
+}
+
 // The same with the explicit stage folded in (FUSE kernels): d <- R0 = T + f*(Lx+Ly+Lz) of this thread's M rows.
 // Preconditions (block-uniform, checked by the caller): the tile is whole -- LINES == 16 active lines, every thread owns
 // M rows of the line (Lp*M == n) -- so no load needs a per-row predicate.  Neighbour loads do not wait for the flags:
@@ -711,23 +764,6 @@ __device__ __forceinline__ double row_bcast(double v, int r)
 #undef ADI_BC
         default: return dpp_mov<0x15f>(0.0, v);
     }
-}
-
-// Buffer addressing (raw_buffer_load/store: 128-bit descriptor + per-thread 32-bit byte offset + scalar byte offset):
-// a strided tile touches M rows x several arrays, and with flat global loads every one of them costs 64-bit address
-// arithmetic in the VALU (measured: half of the fused kernel's VALU instructions); here the row offsets live in
-// scalar registers and one per-thread offset serves every load.
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return __hiloint2double((int)v.y, (int)v.x);
-}
-__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x)
-{
-    u32x2 v;
-    v.x = (unsigned)__double2loint(x); v.y = (unsigned)__double2hiint(x);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
 
 template <int M, bool HAS_DIR>
@@ -880,8 +916,15 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
         lane_fast = fast_segment_load_fused<M, HAS_DIR>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0, kk,
                                                         tbase, fz, d, f0, fS, dirS);
     } else {
-        lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
-                                                  active, d, f0, fS, dirS);
+        // whole tiles whose rows fit 31-bit byte offsets take the buffer-addressed loader (block-uniform choice)
+        const bool whole = kBufStrided && (ti + 1) * LINES <= g.n_inner && Lp * M == g.n &&
+                           (long)g.n * g.stride * 8 < 0x7fffffffL;
+        if (whole)
+            lane_fast = fast_segment_load_buf<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, d,
+                                                          f0, fS, dirS);
+        else
+            lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
+                                                      active, d, f0, fS, dirS);
     }
     if (!__syncthreads_and(lane_fast)) {
         if (tid == 0) enqueue_unit(queue, (unsigned)tile);
@@ -904,7 +947,7 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
     tile_separators(sm, tid, kk, sg, Lp, LINES, aS, bS, cS, d[M - 1], k, xL, xS);
     back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
     double *out_t = out + tbase;
-    if constexpr (FUSE) {
+    if (FUSE || (kBufStrided && (long)g.n * g.stride * 8 < 0x7fffffffL)) {
         const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)out_t, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int r = 0; r < M; ++r) buf_store_f64(rO, voff * 8u, (unsigned)r * (unsigned)(g.stride * 8), d[r]);
@@ -1044,8 +1087,15 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_condense_strid
         lane_fast = fast_segment_load_fused<M, HAS_DIR>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0, kk,
                                                         tbase, fz, d, f0, fS, dirS);
     } else {
-        lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
-                                                  active, d, f0, fS, dirS);
+        // whole tiles whose rows fit 31-bit byte offsets take the buffer-addressed loader (block-uniform choice)
+        const bool whole = kBufStrided && (ti + 1) * LINES <= g.n_inner && Lp * M == g.n &&
+                           (long)g.n * g.stride * 8 < 0x7fffffffL;
+        if (whole)
+            lane_fast = fast_segment_load_buf<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, d,
+                                                          f0, fS, dirS);
+        else
+            lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
+                                                      active, d, f0, fS, dirS);
     }
     if (!__syncthreads_and(lane_fast)) {
         if (tid == 0) enqueue_unit(queue, (unsigned)tile);
@@ -2521,10 +2571,13 @@ static Fuse make_fuse(int nx, int ny, int nz, long plane_stride, double dx, doub
 
 int adi_explicit_fused_supported(int nx, int ny, int nz, long plane_stride, int pass)
 {
-    (void)ny; (void)nz; (void)plane_stride;
     static int off = -1;
     if (off < 0) off = getenv("ADI_NO_FUSE") ? 1 : 0;
-    if (off || nx <= 0) return 0;
+    if (off || nx <= 0 || ny <= 0 || nz <= 0) return 0;
+    // the FAST fused kernel addresses the state through one buffer descriptor (box + a plane either side): beyond
+    // 2 GiB only the GENERAL fused kernel could run, and the separate explicit stage + sweep are faster than that
+    const long sx = plane_stride ? plane_stride : (long)ny * nz;
+    if (((long)nx + 2) * sx * 8 + ((long)nz + 64) * 16 >= 0x7ffff000L) return 0;
     return pass == 0 ? (nx <= kMaxFastLine) : (condense_is_tiled(0, nx) ? 1 : 0);
 }
 
