@@ -28,6 +28,15 @@
 
 namespace adi {
 
+#ifndef ADI_LOAD_AUX
+#define ADI_LOAD_AUX 0      // strided kernels: cache policy of the once-read loads (`in` rows, flags).  nt (2) measured
+#endif                      // SLOWER there: axis-1 sweep 0.41 -> 0.45 ms, axis 0 0.45 -> 0.50 ms
+#ifndef ADI_LOAD_NT_CONTIG
+#define ADI_LOAD_NT_CONTIG 1   // contiguous kernels: streaming (nt) loads of the coalesced rows: 0.42 -> 0.38 ms
+#endif
+#ifndef ADI_STORE_AUX
+#define ADI_STORE_AUX 2     // cache policy of the output stores (2 = nt: streaming; 0 = default)
+#endif
 #ifndef ADI_BUF_STRIDED
 #define ADI_BUF_STRIDED 1   // unfused strided FAST kernels: buffer addressing for whole tiles (0: flat loads)
 #endif
@@ -38,6 +47,29 @@ constexpr bool kBufStrided = ADI_BUF_STRIDED != 0;
 #ifndef ADI_FUSE_OCC
 #define ADI_FUSE_OCC 4   // waves per SIMD the fused FAST kernels are compiled for (4: two 512-thread workgroups per CU)
 #endif
+
+// output fields are written once and not read again by the writing kernel: streaming (nt) stores keep them from
+// displacing the lines other workgroups are about to re-read from L2 (measured on the fused kernel: -3.4 %)
+__device__ __forceinline__ double2 ld_stream2(const double2 *p)
+{
+#if ADI_LOAD_NT_CONTIG
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const d2v w = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
+    return make_double2(w.x, w.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream2(double2 *p, double2 v)
+{
+#if ADI_STORE_AUX == 2
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    d2v w; w.x = v.x; w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<d2v *>(p));
+#else
+    *p = v;
+#endif
+}
 
 struct SweepScal {
     double tg;    // theta * gamma
@@ -142,7 +174,7 @@ __device__ __forceinline__ void load_rows_contig(const double *__restrict__ p, l
             const double2 *q = reinterpret_cast<const double2 *>(p + base);
 #pragma unroll
             for (int i = 0; i < M / 2; ++i) {
-                const double2 t = q[i];
+                const double2 t = q[i];      // lane-owned chunks: several instructions share a 128-byte line -> default policy (nt: 1.01 -> 1.60 ms)
                 v[2 * i] = t.x;
                 v[2 * i + 1] = t.y;
             }
@@ -229,7 +261,7 @@ __device__ __forceinline__ void coal_load(const double *__restrict__ gsrc /* wav
         double2 v[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            v[j] = *reinterpret_cast<const double2 *>(gsrc + h * 32 * M + 128 * j + 2 * lane);
+            v[j] = ld_stream2(reinterpret_cast<const double2 *>(gsrc + h * 32 * M + 128 * j + 2 * lane));
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int e = 128 * j + 2 * lane;           // element inside the half
@@ -266,7 +298,7 @@ __device__ __forceinline__ void coal_store(double *__restrict__ gdst, double *st
         for (int j = 0; j < NJ; ++j) {
             const int e = 128 * j + 2 * lane;
             const double2 t = *reinterpret_cast<const double2 *>(strip + (e / M) * CH + (e % M));
-            *reinterpret_cast<double2 *>(gdst + h * 32 * M + e) = t;
+            st_stream2(reinterpret_cast<double2 *>(gdst + h * 32 * M + e), t);
         }
         wave_lds_fence();
     }
@@ -337,7 +369,7 @@ __device__ __forceinline__ void contig_unit_general(
         if (active && r0 < n) {
             double2 *q = reinterpret_cast<double2 *>(out + base);
 #pragma unroll
-            for (int i = 0; i < M / 2; ++i) q[i] = make_double2(x[2 * i], x[2 * i + 1]);
+            for (int i = 0; i < M / 2; ++i) q[i] = make_double2(x[2 * i], x[2 * i + 1]);   // lane-owned chunks: default policy
         }
     } else {
 #pragma unroll
@@ -453,7 +485,7 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     } else if (VEC) {
         double2 *q = reinterpret_cast<double2 *>(out + base);
 #pragma unroll
-        for (int i = 0; i < M / 2; ++i) q[i] = make_double2(d[2 * i], d[2 * i + 1]);
+        for (int i = 0; i < M / 2; ++i) q[i] = make_double2(d[2 * i], d[2 * i + 1]);   // lane-owned chunks: default policy
     } else {
 #pragma unroll
         for (int r = 0; r < M; ++r) out[base + r] = d[r];
@@ -699,11 +731,16 @@ __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigne
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return __hiloint2double((int)v.y, (int)v.x);
 }
+__device__ __forceinline__ double buf_load_f64_once(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, ADI_LOAD_AUX);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
 __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x)
 {
     u32x2 v;
     v.x = (unsigned)__double2loint(x); v.y = (unsigned)__double2hiint(x);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, ADI_STORE_AUX);
 }
 
 // The same for whole tiles (block-uniform precondition: every lane active, every thread owns M rows), buffer
@@ -721,8 +758,8 @@ __device__ __forceinline__ bool fast_segment_load_buf(const double *__restrict__
     f0 = 0; fS = 0;
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-        const unsigned f = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, 0);
-        d[r] = buf_load_f64(rT, voff * 8u, (unsigned)r * st * 8u);
+        const unsigned f = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, ADI_LOAD_AUX);
+        d[r] = buf_load_f64_once(rT, voff * 8u, (unsigned)r * st * 8u);
         if (r == 0) { f0 = f; lane_fast = lane_fast && ((f & ROW0) == ROW0); }
         else if (r == M - 1) fS = f;
         else lane_fast = lane_fast && ((f & FULL) == FULL);
@@ -789,7 +826,7 @@ __device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict
     unsigned fb[M];
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-        fb[r] = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * (unsigned)g.stride, 0);
+        fb[r] = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * (unsigned)g.stride, ADI_LOAD_AUX);
         d[r] = buf_load_f64(rT, vb, R0 + (unsigned)r * st8);
     }
     const unsigned vw = vb + R0;                                     // this thread's row 0, bytes from the window start
@@ -1945,10 +1982,10 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
         ggrid = grid < 2048u ? grid : 2048u;
     }
     const int ratio = fast ? lwf / lw : 1;
-    // the GENERAL kernel gains nothing measurable from the LDS-transposed access (it is not bound by its access
-    // pattern at 100 VGPRs); kept behind ADI_GENERAL_COAL=1 for experiments
+    // coalesced + LDS-transposed access with streaming loads/stores: 1.01 -> 0.92 ms on the dense general-pack sweep at
+    // 512^3 (with the default cache policy the transposition alone gained nothing); ADI_GENERAL_COAL=0 turns it off
     static int gcoal = -1;
-    if (gcoal < 0) gcoal = getenv("ADI_GENERAL_COAL") ? 1 : 0;
+    if (gcoal < 0) { const char *e = getenv("ADI_GENERAL_COAL"); gcoal = (e && atoi(e) == 0) ? 0 : 1; }
     const bool coal = vec && gcoal && M >= 4 && Lp * M == n && (L.ny % lw == 0) && (nlines % lw == 0);
     if (coal)
         hipLaunchKernelGGL((k_sweep_contig<(M >= 4 ? M : 4), 2, HAS_DIR, HAS_Q>), dim3(ggrid), dim3(256), 0, st, in, flags,
