@@ -1635,7 +1635,7 @@ __global__ __launch_bounds__(256) void k_explicit_v5(const double *__restrict__ 
                 }
                 r1v = tc[r].y + f * ((L0 + L1) + L2);
             }
-            if (kin && rin) *reinterpret_cast<double2 *>(R0 + q) = make_double2(r0v, r1v);
+            if (kin && rin) st_stream2(reinterpret_cast<double2 *>(R0 + q), make_double2(r0v, r1v));
             if (DOTS) {
                 su[r].x = __builtin_fma(wa, r0v, su[r].x); su[r].y = __builtin_fma(wa, r1v, su[r].y);
                 sv[r].x = __builtin_fma(wb, r0v, sv[r].x); sv[r].y = __builtin_fma(wb, r1v, sv[r].y);
