@@ -447,14 +447,19 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     const double co0s = sp0 ? coeff[base] : 0.0, coSs = spS ? coeff[base + M - 1] : 0.0;
     double q0s = 0.0, qSs = 0.0;
     if (HAS_Q) { q0s = sp0 ? qf[base] : 0.0; qSs = spS ? qf[base + M - 1] : 0.0; }
-    bool lane_fast = true;
+    // padding lanes (beyond the end of a line whose segment count is not a power of two, or beyond the last line)
+    // own no rows: they never force the unit to the GENERAL kernel, export an identity block and store nothing
+    const bool pad = !active || r0 >= n;
+    bool lane_fast = true, off = !pad;              // off: every row of the segment is outside the mask (identity rows)
     {
         const unsigned FULL = 1u | (3u << 5), ROW0 = 1u | (1u << 6);
         lane_fast = ((fb[0] & ROW0) == ROW0) && !(HAS_DIR && db[0] != 0);
 #pragma unroll
         for (int r = 1; r < M - 1; ++r) lane_fast = lane_fast && ((fb[r] & FULL) == FULL) && !(HAS_DIR && db[r] != 0);
+#pragma unroll
+        for (int r = 0; r < M; ++r) off = off && !(fb[r] & 1u);
     }
-    if (!__all(lane_fast)) {
+    if (!__all(lane_fast || pad || off)) {
         if (lane == 0) enqueue_unit(queue, (unsigned)unit);
         return;
     }
@@ -473,15 +478,22 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     Cond k;
     double kappa;
     condense_uniform<M>(U, a0, b0, d, k, kappa);
+    if (pad || off) {                               // identity block; an off segment keeps d = in, which it stores back
+        k.gF = k.aF = k.cF = k.gL = k.aL = k.cL = 0.0;
+        kappa = 0.0; aS = 0.0; bS = 1.0; cS = 0.0;
+        if (pad) d[M - 1] = 0.0;
+    }
     const double gFn = __shfl_down(k.gF, 1, Lp), aFn = __shfl_down(k.aF, 1, Lp), cFn = __shfl_down(k.cF, 1, Lp);
     double ra, rb, rc, rd;
     reduced_row(aS, bS, cS, d[M - 1], k, gFn, aFn, cFn, ra, rb, rc, rd);
     const double xS = pcr_solve(ra, rb, rc, rd, li, Lp);
     double xL = __shfl_up(xS, 1, Lp);
     if (li == 0) xL = 0.0;
-    back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
+    if (!off) back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
     if constexpr (MODE == 2) {
-        coal_store<M>(out + wbase, strip, lane, d);
+        coal_store<M>(out + wbase, strip, lane, d);      // (the host takes this mode only when no lane is padding)
+    } else if (pad) {
+        // nothing to store
     } else if (VEC) {
         double2 *q = reinterpret_cast<double2 *>(out + base);
 #pragma unroll
@@ -699,6 +711,10 @@ __device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in_
                                                   int r0, bool active, double (&d)[M], unsigned &f0, unsigned &fS,
                                                   bool &dirS)
 {
+    // a padding segment (r0 >= n: the line has fewer than Lp segments) owns no rows and is always "fast"; so is a
+    // segment whose rows are all outside the mask (identity rows: `off`, reported through f0 = fS = 0 and d = in)
+    const bool pad = active && r0 >= g.n;
+    bool off = active && (r0 + M <= g.n);
     bool lane_fast = active && (r0 + M <= g.n);
     const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
     f0 = 0; fS = 0;
@@ -707,6 +723,7 @@ __device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in_
         const bool ok = active && (r0 + r) < g.n;
         const unsigned f = ok ? (flags_t + (size_t)r * g.stride)[voff] : 0u;
         d[r] = ok ? (in_t + (size_t)r * g.stride)[voff] : 0.0;
+        off = off && !(f & 1u);
         if (r == 0) { f0 = f; lane_fast = lane_fast && ((f & ROW0) == ROW0); }
         else if (r == M - 1) fS = f;
         else lane_fast = lane_fast && ((f & FULL) == FULL);
@@ -715,10 +732,10 @@ __device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in_
     if (HAS_DIR) {
 #pragma unroll
         for (int r = 0; r < M - 1; ++r)
-            lane_fast = lane_fast && ((dmask_t + (size_t)r * g.stride)[voff] == 0);
-        dirS = active && (r0 + M - 1) < g.n && (dmask_t + (size_t)(M - 1) * g.stride)[voff] != 0;
+            lane_fast = lane_fast && (pad || off || (dmask_t + (size_t)r * g.stride)[voff] == 0);
+        dirS = active && !off && (r0 + M - 1) < g.n && (dmask_t + (size_t)(M - 1) * g.stride)[voff] != 0;
     }
-    return lane_fast;
+    return lane_fast || pad || off;
 }
 
 // Buffer addressing (raw_buffer_load/store: 128-bit descriptor + per-thread 32-bit byte offset + scalar byte offset):
@@ -754,12 +771,13 @@ __device__ __forceinline__ bool fast_segment_load_buf(const double *__restrict__
     const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void *)in_t, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void *)flags_t, 0, 0x7fffffff, 0x00020000);
     const unsigned st = (unsigned)g.stride;
-    bool lane_fast = true;
+    bool lane_fast = true, off = true;              // off: all M rows outside the mask
     f0 = 0; fS = 0;
 #pragma unroll
     for (int r = 0; r < M; ++r) {
         const unsigned f = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, ADI_LOAD_AUX);
         d[r] = buf_load_f64_once(rT, voff * 8u, (unsigned)r * st * 8u);
+        off = off && !(f & 1u);
         if (r == 0) { f0 = f; lane_fast = lane_fast && ((f & ROW0) == ROW0); }
         else if (r == M - 1) fS = f;
         else lane_fast = lane_fast && ((f & FULL) == FULL);
@@ -769,10 +787,10 @@ __device__ __forceinline__ bool fast_segment_load_buf(const double *__restrict__
         const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void *)dmask_t, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int r = 0; r < M - 1; ++r)
-            lane_fast = lane_fast && (__builtin_amdgcn_raw_buffer_load_b8(rD, voff, (unsigned)r * st, 0) == 0);
-        dirS = __builtin_amdgcn_raw_buffer_load_b8(rD, voff, (unsigned)(M - 1) * st, 0) != 0;
+            lane_fast = lane_fast && (off || __builtin_amdgcn_raw_buffer_load_b8(rD, voff, (unsigned)r * st, 0) == 0);
+        dirS = !off && __builtin_amdgcn_raw_buffer_load_b8(rD, voff, (unsigned)(M - 1) * st, 0) != 0;
     }
-    return lane_fast;
+    return lane_fast || off;
 }
 
 // The same with the explicit stage folded in (FUSE kernels): d <- R0 = T + f*(Lx+Ly+Lz) of this thread's M rows.
@@ -837,13 +855,15 @@ __device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict
     const unsigned ve = R0 + (unsigned)(r0 + (int)(threadIdx.x & 15u)) * st8;
     const double eL = buf_load_f64(rT, ve - 8u, 0u);
     const double eR = buf_load_f64(rT, ve + LINES * 8u, 0u);
-    bool lane_fast = true, full = true;
+    bool lane_fast = true, full = true, off = true;
 #pragma unroll
     for (int r = 0; r < M; ++r) {
         full = full && (fb[r] == 0x7fu);
+        off = off && !(fb[r] & 1u);
         if (r == 0) lane_fast = lane_fast && ((fb[r] & ROW0) == ROW0);
         else if (r < M - 1) lane_fast = lane_fast && ((fb[r] & FULL) == FULL);
     }
+    lane_fast = lane_fast || off;                   // all rows outside the mask: identity rows, R0 = T
     f0 = fb[0]; fS = fb[M - 1];
     const bool wave_full = __all(full);                     // every cell of this wave has its six neighbours
     // j-neighbour rows: a software pipeline D rows deep (they are L2 hits -- the tiles of the adjacent j-rows run next
@@ -888,8 +908,8 @@ __device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict
     if (HAS_DIR) {
 #pragma unroll
         for (int r = 0; r < M - 1; ++r)
-            lane_fast = lane_fast && ((dmask_t + (size_t)r * g.stride)[voff] == 0);
-        dirS = (dmask_t + (size_t)(M - 1) * g.stride)[voff] != 0;
+            lane_fast = lane_fast && (off || (dmask_t + (size_t)r * g.stride)[voff] == 0);
+        dirS = !off && (dmask_t + (size_t)(M - 1) * g.stride)[voff] != 0;
     }
     return lane_fast;
 }
@@ -943,15 +963,18 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
     // block-uniform tile base (scalar) + one 32-bit per-thread offset for every row of every array
     const long tbase = to * g.outer_stride + (long)ti * LINES;
     const unsigned voff = (unsigned)((long)r0 * g.stride + kk);
+    const bool pad = r0 >= g.n;                    // this thread's segment lies beyond the end of the line
     bool lane_fast;
     if constexpr (FUSE) {
         // whole tiles only (block-uniform): anything else goes to the GENERAL kernel before a single load is issued
-        if (LINES != 16 || (ti + 1) * LINES > g.n_inner || Lp * M != g.n) {
+        if (LINES != 16 || (ti + 1) * LINES > g.n_inner || g.n % M != 0) {
             if (tid == 0) enqueue_unit(queue, (unsigned)tile);
             return;
         }
-        lane_fast = fast_segment_load_fused<M, HAS_DIR>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0, kk,
-                                                        tbase, fz, d, f0, fS, dirS);
+        // a padding segment (line with fewer than Lp segments) re-reads segment 0 -- valid addresses, values unused
+        const int r0e = pad ? 0 : r0;
+        lane_fast = fast_segment_load_fused<M, HAS_DIR>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g,
+                                                        pad ? (unsigned)kk : voff, r0e, kk, tbase, fz, d, f0, fS, dirS) || pad;
     } else {
         // whole tiles whose rows fit 31-bit byte offsets take the buffer-addressed loader (block-uniform choice)
         const bool whole = kBufStrided && (ti + 1) * LINES <= g.n_inner && Lp * M == g.n &&
@@ -980,9 +1003,18 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
     Cond k;
     double kappa;
     condense_uniform<M>(U, a0, b0, d, k, kappa);
+    // a segment outside the mask (every flag has bit 0 clear; the only other way past the tile vote without the
+    // in-mask first row of a uniform segment): identity rows, x = in
+    const bool off = !pad && !(f0 & 1u);
+    if (pad || off) {                              // identity block: nothing reaches the real segments
+        k.gF = k.aF = k.cF = k.gL = k.aL = k.cL = 0.0;
+        kappa = 0.0; aS = 0.0; bS = 1.0; cS = 0.0;
+        if (pad) d[M - 1] = 0.0;
+    }
     double xL, xS;
     tile_separators(sm, tid, kk, sg, Lp, LINES, aS, bS, cS, d[M - 1], k, xL, xS);
-    back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
+    if (!off) back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
+    if (pad) return;                               // (after the last barrier)
     double *out_t = out + tbase;
     if (FUSE || (kBufStrided && (long)g.n * g.stride * 8 < 0x7fffffffL)) {
         const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)out_t, 0, 0x7fffffff, 0x00020000);
@@ -1114,15 +1146,18 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_condense_strid
     // block-uniform tile base (scalar) + one 32-bit per-thread offset for every row of every array
     const long tbase = to * g.outer_stride + (long)ti * LINES;
     const unsigned voff = (unsigned)((long)r0 * g.stride + kk);
+    const bool pad = r0 >= g.n;                    // this thread's segment lies beyond the end of the line
     bool lane_fast;
     if constexpr (FUSE) {
         // whole tiles only (block-uniform): anything else goes to the GENERAL kernel before a single load is issued
-        if (LINES != 16 || (ti + 1) * LINES > g.n_inner || Lp * M != g.n) {
+        if (LINES != 16 || (ti + 1) * LINES > g.n_inner || g.n % M != 0) {
             if (tid == 0) enqueue_unit(queue, (unsigned)tile);
             return;
         }
-        lane_fast = fast_segment_load_fused<M, HAS_DIR>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0, kk,
-                                                        tbase, fz, d, f0, fS, dirS);
+        // a padding segment (line with fewer than Lp segments) re-reads segment 0 -- valid addresses, values unused
+        const int r0e = pad ? 0 : r0;
+        lane_fast = fast_segment_load_fused<M, HAS_DIR>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g,
+                                                        pad ? (unsigned)kk : voff, r0e, kk, tbase, fz, d, f0, fS, dirS) || pad;
     } else {
         // whole tiles whose rows fit 31-bit byte offsets take the buffer-addressed loader (block-uniform choice)
         const bool whole = kBufStrided && (ti + 1) * LINES <= g.n_inner && Lp * M == g.n &&
@@ -1139,7 +1174,7 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_condense_strid
         return;
     }
     if constexpr (FUSE) {
-        if (fz.r0_out != nullptr) {
+        if (fz.r0_out != nullptr && !pad) {
             const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)(fz.r0_out + tbase), 0, 0x7fffffff,
                                                                                 0x00020000);
 #pragma unroll
@@ -1151,6 +1186,14 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_condense_strid
     Cond ki;
     double kappa;
     condense_uniform<M>(U, a0, b0, d, ki, kappa);
+    if (pad) {                                     // finite values; tile_reduce_store ignores blocks >= n / M
+        ki.gF = ki.aF = ki.cF = ki.gL = ki.aL = ki.cL = 0.0;
+        aS = 0.0; bS = 1.0; cS = 0.0; d[M - 1] = 0.0;
+    } else if (!(f0 & 1u)) {                       // segment outside the mask: M identity rows
+        ki.gF = d[0]; ki.gL = d[M - 2];
+        ki.aF = ki.cF = ki.aL = ki.cL = 0.0;
+        aS = 0.0; bS = 1.0; cS = 0.0;
+    }
     const double ib = frcp(bS);
     Cond rowc;
     rowc.gF = rowc.gL = d[M - 1] * ib;

@@ -45,6 +45,10 @@ struct adi_cyl_plan {
     double zT0, zTN;             // dirichlet values
 };
 
+#ifndef ADI_CYL_NT
+#define ADI_CYL_NT 1
+#endif
+
 namespace adi {
 
 struct CylZ {
@@ -163,7 +167,13 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_cyl_strided(
     }
 #pragma unroll
     for (int r = 0; r < M; ++r)
-        if (active && (r0 + r) < n) out[base + (long)(r0 + r) * stride] = x[r];
+        if (active && (r0 + r) < n) {
+#if ADI_CYL_NT
+            __builtin_nontemporal_store(x[r], out + base + (long)(r0 + r) * stride);   // written once, whole 128-byte pieces
+#else
+            out[base + (long)(r0 + r) * stride] = x[r];
+#endif
+        }
 }
 
 // ---- z sweep: contiguous kernel, constant coefficients with end closures -----------------------

@@ -120,7 +120,9 @@ def test_cyl_bad_kind(hipcyl):
         run_cyl_case(hipcyl, c)
 
 
-@pytest.mark.parametrize('shape', [(512, 6, 24), (6, 24, 512), (10, 512, 16), (256, 8, 256)])
+@pytest.mark.parametrize('shape', [(512, 6, 24), (6, 24, 512), (10, 512, 16), (256, 8, 256),
+                                   # segment counts that are not powers of two: padding lanes / segments in the FAST kernels
+                                   (320, 6, 32), (6, 20, 320), (10, 384, 16), (192, 4, 96), (5, 3, 200), (200, 3, 16)])
 def test_long_lines_fast_and_general_units(hip, shape):
     """lines of 256/512 rows (M = 4/8, 64 lanes per line): mostly solid, so the FAST kernels take most units, with
     holes, a Dirichlet plane, a Neumann face and Robin everywhere forcing queued GENERAL units in the same sweep"""
@@ -235,6 +237,7 @@ def test_very_long_lines(hip, shape):
 
 
 @pytest.mark.parametrize('shape,fill', [((512, 6, 40), 1.0), ((512, 5, 32), 0.97), ((256, 3, 64), 1.0), ((64, 33, 48), 0.9), ((257, 4, 18), 1.0),
+                                        ((320, 4, 32), 1.0), ((384, 3, 16), 0.98), ((96, 5, 48), 1.0),
                                         ((16, 16, 16), 0.8), ((128, 9, 130), 1.0), ((3, 7, 5), 0.7), ((1, 4, 6), 1.0)])
 @pytest.mark.parametrize('bc', ['lean', 'general'])
 def test_fused_explicit_sweep0_is_bit_identical(hip, shape, fill, bc):
