@@ -217,6 +217,13 @@ def main():
     )
     if xs is not None:
         line['general_pack_sweeps_42B'] = xs
+        # BASELINE.json's target is written against this kernel: ">= 60 % of MI355X HBM peak on the x-sweep batched
+        # Thomas solve for a 512^3 fp64 Cartesian grid at 1 GPU" (x = the contiguous axis), the reference's own data model
+        x = xs['sweep_axis2_contig']
+        line['north_star_x_sweep'] = dict(kernel='sweep_axis2_contig, general pack (42 B/cell, every array read in full)',
+                                          achieved=x['achieved_gbs'], peak=HBM_PEAK_GBS, unit='GB/s', frac=x['frac'],
+                                          target_frac=0.60,
+                                          lean_sparse_variant_in_step=kernels.get('sweep_axis2_contig'))
     if world == 1 and not rehearse and not a.no_cpu:
         st, mt = cpu_baseline(a.cpu_n)
         line['cpu_baseline'] = st
