@@ -86,6 +86,80 @@ __device__ __forceinline__ bool axis_exposed(unsigned f, int lbit)
     return (f & 1u) && (((f >> lbit) & 3u) != 3u);
 }
 
+// Segment classes of the FAST kernels (M rows: block rows 0..M-2 + separator row M-1), from the in-mask bits of its rows:
+//   UNI   the uniform-interior segment of section 3.2        OFF  every row outside the mask (identity rows)
+//   PAD   beyond the end of the line (no rows)
+//   TAIL  block rows [M-1-L, M-1) in the mask down to the in-mask separator, the rows above them outside: the line
+//         STARTS inside the segment        HEAD  block rows [0, L) in the mask below an in-mask previous row, the rest
+//         of the segment (separator included) outside: the line ENDS inside the segment.   (adi_core.hpp, mixed_*)
+enum { SEG_NONE = 0, SEG_UNI = 1, SEG_OFF = 2, SEG_PAD = 3, SEG_TAIL = 4, SEG_HEAD = 5 };
+
+template <int M>
+__device__ __forceinline__ int classify_mixed(unsigned inm, unsigned f0, int lbit, int &L)
+{
+    constexpr int MI = M - 1;
+    const unsigned ALL = (1u << M) - 1u;
+    L = 0;
+    if (inm == 0u) return SEG_OFF;
+    if ((inm >> MI) & 1u) {                        // separator in the mask: rows [m, M) in, [0, m) out, 1 <= m <= MI
+        const int m = __ffs(inm) - 1;
+        if (m >= 1 && inm == (ALL & ~((1u << m) - 1u))) { L = MI - m; return SEG_TAIL; }
+    } else {                                       // separator outside: rows [0, e) in, previous row in the mask
+        const int e = __popc(inm);
+        if (inm == ((1u << e) - 1u) && ((f0 >> lbit) & 1u)) { L = e; return SEG_HEAD; }
+    }
+    return SEG_NONE;
+}
+
+// What a mixed lane does instead of condense_uniform (shared by the FAST kernels).  row0p: pointer to this thread's row
+// 0 in coeff / qflux (rows `rstride` elements apart).  On entry d = the incoming values with rows 0 and M-1 already
+// assembled (a0, b0 belong to row 0); on exit d[modified row] = its assembled right-hand side, bmod = its diagonal and
+// k = the segment's condensation.
+template <int M, bool HAS_Q>
+__device__ __forceinline__ void mixed_lane_condense(int kind, int L, const UniC<M> &U, const SweepScal &s,
+                                                    const double *__restrict__ coeff0, const double *__restrict__ qf0,
+                                                    long rstride, double a0, double b0, double (&d)[M], double &bmod,
+                                                    Cond &k)
+{
+    constexpr int MI = M - 1;
+    const bool tail = kind == SEG_TAIL;
+    const int rmod = tail ? MI - L : L - 1;                 // the line-start / line-end row of the run
+    bmod = b0;                                              // head run of one row: row 0 is that row, already assembled
+    if (L >= 1 && (tail || rmod > 0)) {
+        const double co = coeff0[(long)rmod * rstride];     // exposed along the axis: carries the Robin coefficient
+        const double q = HAS_Q ? qf0[(long)rmod * rstride] : 0.0;
+        double din = 0.0;
+#pragma unroll
+        for (int r = 1; r < MI; ++r) din = (r == rmod) ? d[r] : din;
+        double am, cm, dm;
+        assemble_row<false, HAS_Q>(true, !tail, tail, false, din, co, 0.0, q, s, am, bmod, cm, dm);
+#pragma unroll
+        for (int r = 1; r < MI; ++r) d[r] = (r == rmod) ? dm : d[r];
+    }
+    double G = 0.0, A = 0.0;
+    if (tail) {
+        if (L >= 1) mixed_condense<M, true>(U, d, L, bmod, U.s, G, A);
+        k.gF = d[0]; k.aF = 0.0; k.cF = 0.0;                // row 0 is outside the mask (m >= 1)
+        k.gL = (L >= 1) ? G : d[MI - 1]; k.aL = 0.0; k.cL = (L >= 1) ? A : 0.0;
+    } else {
+        mixed_condense<M, false>(U, d, L, bmod, a0, G, A);
+        k.gF = G; k.aF = A; k.cF = 0.0;
+        k.gL = 0.0; k.aL = 0.0; k.cL = 0.0;                 // the separator row is outside the mask: a_S = 0
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void mixed_lane_back_solve(int kind, int L, const UniC<M> &U, double bmod, double a0,
+                                                      double (&d)[M], double xL, double xS)
+{
+    if (kind == SEG_TAIL) {
+        if (L >= 1) mixed_back_solve<M, true>(U, d, L, bmod, U.s, xS);
+        d[M - 1] = xS;
+    } else {
+        mixed_back_solve<M, false>(U, d, L, bmod, a0, xL);
+    }
+}
+
 // One axis of lap1D_x/y/z (adi3d_numba_coeff.py:240-288) in the reference's evaluation order.
 __device__ __forceinline__ double lap_axis(bool lo, bool hi, double tlo, double thi, double t, double invdx2)
 {
@@ -450,16 +524,27 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     // padding lanes (beyond the end of a line whose segment count is not a power of two, or beyond the last line)
     // own no rows: they never force the unit to the GENERAL kernel, export an identity block and store nothing
     const bool pad = !active || r0 >= n;
-    bool lane_fast = true, off = !pad;              // off: every row of the segment is outside the mask (identity rows)
+    int kind = SEG_NONE, Lm = 0;                    // segment class of this lane (classify_mixed) and length of a mixed run
     {
         const unsigned FULL = 1u | (3u << 5), ROW0 = 1u | (1u << 6);
-        lane_fast = ((fb[0] & ROW0) == ROW0) && !(HAS_DIR && db[0] != 0);
+        bool uni = ((fb[0] & ROW0) == ROW0) && !(HAS_DIR && db[0] != 0), nodir = !(HAS_DIR && db[0] != 0);
+        unsigned inm = fb[0] & 1u;
 #pragma unroll
-        for (int r = 1; r < M - 1; ++r) lane_fast = lane_fast && ((fb[r] & FULL) == FULL) && !(HAS_DIR && db[r] != 0);
+        for (int r = 1; r < M - 1; ++r) {
+            uni = uni && ((fb[r] & FULL) == FULL) && !(HAS_DIR && db[r] != 0);
+            nodir = nodir && !(HAS_DIR && db[r] != 0);
+        }
 #pragma unroll
-        for (int r = 0; r < M; ++r) off = off && !(fb[r] & 1u);
+        for (int r = 1; r < M; ++r) inm |= (fb[r] & 1u) << r;
+        if (pad) kind = SEG_PAD;
+        else if (uni) kind = SEG_UNI;
+        else {
+            kind = classify_mixed<M>(inm, fb[0], 5, Lm);
+            if (kind >= SEG_TAIL && !nodir) kind = SEG_NONE;
+        }
     }
-    if (!__all(lane_fast || pad || off)) {
+    const bool off = kind == SEG_OFF;
+    if (!__all(kind != SEG_NONE)) {
         if (lane == 0) enqueue_unit(queue, (unsigned)unit);
         return;
     }
@@ -483,13 +568,16 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
         kappa = 0.0; aS = 0.0; bS = 1.0; cS = 0.0;
         if (pad) d[M - 1] = 0.0;
     }
+    double bmod = 1.0;
+    if (kind >= SEG_TAIL) mixed_lane_condense<M, HAS_Q>(kind, Lm, U, s, coeff + base, qf + base, 1L, a0, b0, d, bmod, k);
     const double gFn = __shfl_down(k.gF, 1, Lp), aFn = __shfl_down(k.aF, 1, Lp), cFn = __shfl_down(k.cF, 1, Lp);
     double ra, rb, rc, rd;
     reduced_row(aS, bS, cS, d[M - 1], k, gFn, aFn, cFn, ra, rb, rc, rd);
     const double xS = pcr_solve(ra, rb, rc, rd, li, Lp);
     double xL = __shfl_up(xS, 1, Lp);
     if (li == 0) xL = 0.0;
-    if (!off) back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
+    if (kind == SEG_UNI || kind == SEG_PAD) back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
+    else if (kind >= SEG_TAIL) mixed_lane_back_solve<M>(kind, Lm, U, bmod, a0, d, xL, xS);
     if constexpr (MODE == 2) {
         coal_store<M>(out + wbase, strip, lane, d);      // (the host takes this mode only when no lane is padding)
     } else if (pad) {

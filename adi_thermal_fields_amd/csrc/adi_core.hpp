@@ -189,6 +189,71 @@ __device__ __forceinline__ void back_solve_uniform(const UniC<M> &U, double a0, 
     d[M - 1] = xS;
 }
 
+// ---- mixed segments: the surface of the solid crosses the segment once ----------------------------------------
+// Inside the block (rows 0..M-2) an in-mask run of L rows is coupled to ONE outside unknown through a uniform row at
+// one end and stops in a line-start / line-end row (only one neighbour in the mask, b = bmod) at the other end; the
+// rest of the block is outside the mask (identity rows).
+//   REV = true  ("tail"): run = rows [M-1-L, M-1), coupled to the separator row x_S below it, line start at row M-1-L
+//   REV = false ("head"): run = rows [0, L),       coupled to x_prev above it (coefficient a_c),  line end at row L-1
+// q = 0..L-1 counts rows from the coupled end; row(q) = REV ? M-2-q : q.  Lanes of this kind are rare (two per line
+// crossing the solid), so they may afford what the uniform path avoids: one reciprocal chain along the run.
+template <int M, bool REV>
+__device__ __forceinline__ double &mixed_row(double (&d)[M], int q) { return d[REV ? (M - 2 - q) : q]; }
+
+// x_(q=0) = G - A * x_out  (elimination from the modified end towards the coupled end; O(1) state)
+template <int M, bool REV>
+__device__ __forceinline__ void mixed_condense(const UniC<M> &U, double (&d)[M], int L, double bmod, double a_c,
+                                               double &G, double &A)
+{
+    constexpr int MI = M - 1;
+    double P = 1.0, g = 0.0;
+#pragma unroll
+    for (int q = MI - 1; q >= 0; --q) {
+        const double dq = mixed_row<M, REV>(d, q);
+        if (q == L - 1) { P = bmod; g = dq; }
+        else if (q < L - 1) {
+            const double w = U.s * frcp(P);
+            P = __builtin_fma(-w, U.s, U.bu);
+            g = __builtin_fma(-w, g, dq);
+        }
+    }
+    const double iP = frcp(P);
+    G = g * iP;
+    A = a_c * iP;
+}
+
+// in place: rows of the run <- solution, given the outside unknown; Thomas from the coupled end with the prefix
+// factors of the uniform block (w, ip) and one modified pivot at the far end
+template <int M, bool REV>
+__device__ __forceinline__ void mixed_back_solve(const UniC<M> &U, double (&d)[M], int L, double bmod, double a_c,
+                                                 double x_out)
+{
+    constexpr int MI = M - 1;
+    double y = 0.0;
+#pragma unroll
+    for (int q = 0; q < MI; ++q) {
+        if (q < L) {
+            double &dq = mixed_row<M, REV>(d, q);
+            y = (q == 0) ? __builtin_fma(-a_c, x_out, dq) : __builtin_fma(-U.w[q], y, dq);
+            dq = y;
+        }
+    }
+    double xn = 0.0;
+#pragma unroll
+    for (int q = MI - 1; q >= 0; --q) {
+        if (q < L) {
+            double &dq = mixed_row<M, REV>(d, q);
+            if (q == L - 1) {
+                const double delta = bmod - U.bu;
+                xn = dq * (U.ip[q] * frcp(__builtin_fma(delta, U.ip[q], 1.0)));      // 1 / (1/ip + delta)
+            } else {
+                xn = __builtin_fma(-U.s, xn, dq) * U.ip[q];
+            }
+            dq = xn;
+        }
+    }
+}
+
 // host: constants for (s, bu)
 template <int M>
 inline UniC<M> make_unic(double tg)

@@ -315,3 +315,37 @@ def test_graph_replayed_nsub_loop_matches_plain_steps(hip, shape, nsteps):
     packs = hip.precompute_coeff_packs_unified(grid, mat, robin_h=300.0, neumann={'z-': 1e5})
     st = hip.StagedStepper(grid, mat, prm, packs, Tinf=25.0)
     assert np.array_equal(st.run(got2, 4).get(), plain(got2, 4))
+
+
+def _ellipsoid(shape, holes=False):
+    g = np.meshgrid(*[(np.arange(n) + 0.5) / n - 0.5 for n in shape], indexing='ij')
+    m = (g[0] / 0.46) ** 2 + (g[1] / 0.42) ** 2 + (g[2] / 0.47) ** 2 <= 1.0
+    if holes:
+        m &= ~(((g[0] - 0.1) / 0.12) ** 2 + (g[1] / 0.15) ** 2 + ((g[2] + 0.05) / 0.1) ** 2 <= 1.0)   # an inner void
+    return m
+
+
+@pytest.mark.parametrize('shape', [(512, 40, 48), (48, 512, 32), (40, 48, 512), (320, 24, 320), (96, 80, 96)])
+@pytest.mark.parametrize('bc', ['lean', 'neumann', 'general'])
+def test_curved_solids_surface_segments(hip, shape, bc):
+    """ellipsoids (with an inner void): every line through the solid starts and ends inside a register segment, the
+    case the FAST kernels take as TAIL / HEAD segments (one reciprocal chain along the run) instead of queueing the unit;
+    long lines along each axis in turn so that the 8- and 16-row tilings of all three kernel families see them"""
+    from oracle import adi_oracle as orc
+    rng = np.random.default_rng(sum(shape) + len(bc))
+    mask = _ellipsoid(shape, holes=(bc != 'lean'))
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    kw = dict(dir_mask=None, dir_value=None, neumann=None)
+    if bc != 'lean':
+        kw['neumann'] = {'x-': 2e5, 'y+': rng.uniform(0, 1e5, shape), 'z-': 1.5e5}
+    if bc == 'general':
+        dm = np.zeros(shape, bool); dm[:, :, : shape[2] // 3] = mask[:, :, : shape[2] // 3] & (rng.random(mask[:, :, : shape[2] // 3].shape) < 0.02)
+        kw.update(dir_mask=dm, dir_value=rng.uniform(30.0, 60.0, shape))
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,
+             T0=rng.uniform(20.0, 1200.0, shape), robin_h=rng.uniform(20.0, 400.0, shape), Tinf=20.0, theta=0.5,
+             dt=120.0 * dx * dx / alpha, nsteps=2, births=None, **kw)
+    got = run_cart_case(hip, c)['T_final']
+    want = run_cart_case(orc, c)['T_final']
+    assert rel_linf(got, want) <= TOL, rel_linf(got, want)
+    assert np.array_equal(got[~mask], c['T0'][~mask])
