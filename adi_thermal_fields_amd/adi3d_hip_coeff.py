@@ -226,6 +226,7 @@ class Grid3D:
         check(lib.adi_build_nbr_flags(_p(self._d_mask), self.nx, self.ny, self.nz, self.sx, _p(self._d_flags),
                                       _stream()))
         self.mask_version += 1
+        self.all_solid = bool(np.asarray(self._mask).all())     # hint for the kernels: no surface inside the box
         return self._d_mask
 
     @property
@@ -439,7 +440,8 @@ def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None, 
     v = pack.variant if variant is None else variant
     check(lib.adi_sweep(axis, v, _p(t_in), _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
                         _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
-                        int(pack.sparse_ok and not dense), params.theta, gam, params.dt, float(Tinf), _p(t_out),
+                        int(pack.sparse_ok and not dense) | (2 if getattr(grid, 'all_solid', False) else 0), params.theta,
+                        gam, params.dt, float(Tinf), _p(t_out),
                         _p(xlo), _p(xhi),
                         _p(work), wb, _stream()))
 
@@ -465,7 +467,8 @@ def _explicit_sweep0_into(t, t_out, grid, mat, params, pack, Tinf, variant=None,
     vlo, vhi = valid_range(t)
     check(lib.adi_explicit_sweep0(v, _p(t), vlo, vhi, _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
                                   _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
-                                  int(pack.sparse_ok and not dense), grid.dx, params.dt, kappa, params.theta,
+                                  int(pack.sparse_ok and not dense) | (2 if getattr(grid, 'all_solid', False) else 0),
+                                  grid.dx, params.dt, kappa, params.theta,
                                   float(Tinf), _p(t_out), None, None, _p(work), wb, _stream()))
 
 

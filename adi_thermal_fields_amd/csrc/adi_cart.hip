@@ -75,6 +75,9 @@ struct SweepScal {
     double tg;    // theta * gamma
     double dt;
     double Tinf;
+    int box;      // hint (bit 1 of the ABI's `sparse` argument): every cell of the box is in the mask, so no surface
+                  // crosses a segment; the fused FAST kernel then runs its build without the TAIL / HEAD lanes
+                  // (12 more registers fit the 128-VGPR budget: 0.69 instead of 0.80 ms at 512^3)
     int sparse;   // 1: coeff / qflux are non-zero only on cells exposed along the sweep axis (packs built by
                   //    adi_build_coeffs), so they are loaded only there; dir_val only where dir_mask is set
 };
@@ -98,7 +101,7 @@ template <int M>
 __device__ __forceinline__ int classify_mixed(unsigned inm, unsigned f0, int lbit, int &L)
 {
     constexpr int MI = M - 1;
-    const unsigned ALL = (1u << M) - 1u;
+    const unsigned ALL = (M >= 32) ? 0xffffffffu : ((1u << (M & 31)) - 1u);
     L = 0;
     if (inm == 0u) return SEG_OFF;
     if ((inm >> MI) & 1u) {                        // separator in the mask: rows [m, M) in, [0, m) out, 1 <= m <= MI
@@ -109,55 +112,6 @@ __device__ __forceinline__ int classify_mixed(unsigned inm, unsigned f0, int lbi
         if (inm == ((1u << e) - 1u) && ((f0 >> lbit) & 1u)) { L = e; return SEG_HEAD; }
     }
     return SEG_NONE;
-}
-
-// What a mixed lane does instead of condense_uniform (shared by the FAST kernels).  row0p: pointer to this thread's row
-// 0 in coeff / qflux (rows `rstride` elements apart).  On entry d = the incoming values with rows 0 and M-1 already
-// assembled (a0, b0 belong to row 0); on exit d[modified row] = its assembled right-hand side, bmod = its diagonal and
-// k = the segment's condensation.
-template <int M, bool HAS_Q>
-__device__ __forceinline__ void mixed_lane_condense(int kind, int L, const UniC<M> &U, const SweepScal &s,
-                                                    const double *__restrict__ coeff0, const double *__restrict__ qf0,
-                                                    long rstride, double a0, double b0, double (&d)[M], double &bmod,
-                                                    Cond &k)
-{
-    constexpr int MI = M - 1;
-    const bool tail = kind == SEG_TAIL;
-    const int rmod = tail ? MI - L : L - 1;                 // the line-start / line-end row of the run
-    bmod = b0;                                              // head run of one row: row 0 is that row, already assembled
-    if (L >= 1 && (tail || rmod > 0)) {
-        const double co = coeff0[(long)rmod * rstride];     // exposed along the axis: carries the Robin coefficient
-        const double q = HAS_Q ? qf0[(long)rmod * rstride] : 0.0;
-        double din = 0.0;
-#pragma unroll
-        for (int r = 1; r < MI; ++r) din = (r == rmod) ? d[r] : din;
-        double am, cm, dm;
-        assemble_row<false, HAS_Q>(true, !tail, tail, false, din, co, 0.0, q, s, am, bmod, cm, dm);
-#pragma unroll
-        for (int r = 1; r < MI; ++r) d[r] = (r == rmod) ? dm : d[r];
-    }
-    double G = 0.0, A = 0.0;
-    if (tail) {
-        if (L >= 1) mixed_condense<M, true>(U, d, L, bmod, U.s, G, A);
-        k.gF = d[0]; k.aF = 0.0; k.cF = 0.0;                // row 0 is outside the mask (m >= 1)
-        k.gL = (L >= 1) ? G : d[MI - 1]; k.aL = 0.0; k.cL = (L >= 1) ? A : 0.0;
-    } else {
-        mixed_condense<M, false>(U, d, L, bmod, a0, G, A);
-        k.gF = G; k.aF = A; k.cF = 0.0;
-        k.gL = 0.0; k.aL = 0.0; k.cL = 0.0;                 // the separator row is outside the mask: a_S = 0
-    }
-}
-
-template <int M>
-__device__ __forceinline__ void mixed_lane_back_solve(int kind, int L, const UniC<M> &U, double bmod, double a0,
-                                                      double (&d)[M], double xL, double xS)
-{
-    if (kind == SEG_TAIL) {
-        if (L >= 1) mixed_back_solve<M, true>(U, d, L, bmod, U.s, xS);
-        d[M - 1] = xS;
-    } else {
-        mixed_back_solve<M, false>(U, d, L, bmod, a0, xL);
-    }
 }
 
 // One axis of lap1D_x/y/z (adi3d_numba_coeff.py:240-288) in the reference's evaluation order.
@@ -231,6 +185,55 @@ __device__ __forceinline__ void assemble_row(bool m, bool mL, bool mR, bool dir,
     if (HAS_Q) rhs = rhs + s.dt * q;
     rhs = rhs + dc * s.Tinf;
     d = fr ? rhs : ((HAS_DIR && m) ? dv : in);
+}
+
+// What a mixed lane does instead of condense_uniform (shared by the FAST kernels).  row0p: pointer to this thread's row
+// 0 in coeff / qflux (rows `rstride` elements apart).  On entry d = the incoming values with rows 0 and M-1 already
+// assembled (a0, b0 belong to row 0); on exit d[modified row] = its assembled right-hand side, bmod = its diagonal and
+// k = the segment's condensation.
+template <int M, bool HAS_Q>
+__device__ __forceinline__ void mixed_lane_condense(int kind, int L, const UniC<M> &U, const SweepScal &s,
+                                                    const double *__restrict__ coeff0, const double *__restrict__ qf0,
+                                                    long rstride, double a0, double b0, double (&d)[M], double &bmod,
+                                                    Cond &k)
+{
+    constexpr int MI = M - 1;
+    const bool tail = kind == SEG_TAIL;
+    const int rmod = tail ? MI - L : L - 1;                 // the line-start / line-end row of the run
+    bmod = b0;                                              // head run of one row: row 0 is that row, already assembled
+    if (L >= 1 && (tail || rmod > 0)) {
+        const double co = coeff0[(long)rmod * rstride];     // exposed along the axis: carries the Robin coefficient
+        const double q = HAS_Q ? qf0[(long)rmod * rstride] : 0.0;
+        double din = 0.0;
+#pragma unroll
+        for (int r = 1; r < MI; ++r) din = (r == rmod) ? d[r] : din;
+        double am, cm, dm;
+        assemble_row<false, HAS_Q>(true, !tail, tail, false, din, co, 0.0, q, s, am, bmod, cm, dm);
+#pragma unroll
+        for (int r = 1; r < MI; ++r) d[r] = (r == rmod) ? dm : d[r];
+    }
+    double G = 0.0, A = 0.0;
+    if (tail) {
+        if (L >= 1) mixed_condense<M, true>(U, d, L, bmod, U.s, G, A);
+        k.gF = d[0]; k.aF = 0.0; k.cF = 0.0;                // row 0 is outside the mask (m >= 1)
+        k.gL = (L >= 1) ? G : d[MI - 1]; k.aL = 0.0; k.cL = (L >= 1) ? A : 0.0;
+    } else {
+        mixed_condense<M, false>(U, d, L, bmod, a0, G, A);
+        k.gF = G; k.aF = A; k.cF = 0.0;
+        k.gL = 0.0; k.aL = 0.0; k.cL = 0.0;                 // the separator row is outside the mask: a_S = 0
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void mixed_lane_back_solve(int kind, int L, const UniC<M> &U, double bmod, double a0,
+                                                      double (&d)[M], double xL, double xS)
+{
+    if (kind == SEG_TAIL) {
+        if (L >= 1) mixed_back_solve<M, true>(U, d, L, bmod, U.s, xS);
+        d[M - 1] = xS;
+    } else {
+        mixed_back_solve<M, false>(U, d, L, bmod, a0, xL);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -797,33 +800,42 @@ template <int M, bool HAS_DIR>
 __device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in_t, const uint8_t *__restrict__ flags_t,
                                                   const uint8_t *__restrict__ dmask_t, const LineGeom &g, unsigned voff,
                                                   int r0, bool active, double (&d)[M], unsigned &f0, unsigned &fS,
-                                                  bool &dirS)
+                                                  bool &dirS, int &kind, int &Lm)
 {
-    // a padding segment (r0 >= n: the line has fewer than Lp segments) owns no rows and is always "fast"; so is a
-    // segment whose rows are all outside the mask (identity rows: `off`, reported through f0 = fS = 0 and d = in)
+    // kind: the segment class (SEG_*): a padding segment (r0 >= n: the line has fewer than Lp segments) owns no rows, a
+    // segment whose rows are all outside the mask is M identity rows, TAIL / HEAD are crossed by the surface once
     const bool pad = active && r0 >= g.n;
-    bool off = active && (r0 + M <= g.n);
-    bool lane_fast = active && (r0 + M <= g.n);
+    bool uni = active && (r0 + M <= g.n);
     const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
     f0 = 0; fS = 0;
+    unsigned inm = 0;
 #pragma unroll
     for (int r = 0; r < M; ++r) {
         const bool ok = active && (r0 + r) < g.n;
         const unsigned f = ok ? (flags_t + (size_t)r * g.stride)[voff] : 0u;
         d[r] = ok ? (in_t + (size_t)r * g.stride)[voff] : 0.0;
-        off = off && !(f & 1u);
-        if (r == 0) { f0 = f; lane_fast = lane_fast && ((f & ROW0) == ROW0); }
+        inm |= (f & 1u) << r;
+        if (r == 0) { f0 = f; uni = uni && ((f & ROW0) == ROW0); }
         else if (r == M - 1) fS = f;
-        else lane_fast = lane_fast && ((f & FULL) == FULL);
+        else uni = uni && ((f & FULL) == FULL);
     }
+    bool nodir = true;
     dirS = false;
     if (HAS_DIR) {
 #pragma unroll
         for (int r = 0; r < M - 1; ++r)
-            lane_fast = lane_fast && (pad || off || (dmask_t + (size_t)r * g.stride)[voff] == 0);
-        dirS = active && !off && (r0 + M - 1) < g.n && (dmask_t + (size_t)(M - 1) * g.stride)[voff] != 0;
+            nodir = nodir && (pad || inm == 0u || (dmask_t + (size_t)r * g.stride)[voff] == 0);
+        dirS = active && inm != 0u && (r0 + M - 1) < g.n && (dmask_t + (size_t)(M - 1) * g.stride)[voff] != 0;
     }
-    return lane_fast || pad || off;
+    Lm = 0;
+    if (pad) kind = SEG_PAD;
+    else if (!active || r0 + M > g.n) kind = SEG_NONE;
+    else if (uni) kind = nodir ? SEG_UNI : SEG_NONE;
+    else {
+        kind = classify_mixed<M>(inm, f0, g.lbit, Lm);
+        if (kind >= SEG_TAIL && !nodir) kind = SEG_NONE;
+    }
+    return kind != SEG_NONE;
 }
 
 // Buffer addressing (raw_buffer_load/store: 128-bit descriptor + per-thread 32-bit byte offset + scalar byte offset):
@@ -853,32 +865,41 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned
 template <int M, bool HAS_DIR>
 __device__ __forceinline__ bool fast_segment_load_buf(const double *__restrict__ in_t, const uint8_t *__restrict__ flags_t,
                                                       const uint8_t *__restrict__ dmask_t, const LineGeom &g, unsigned voff,
-                                                      double (&d)[M], unsigned &f0, unsigned &fS, bool &dirS)
+                                                      double (&d)[M], unsigned &f0, unsigned &fS, bool &dirS, int &kind,
+                                                      int &Lm)
 {
     const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
     const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void *)in_t, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void *)flags_t, 0, 0x7fffffff, 0x00020000);
     const unsigned st = (unsigned)g.stride;
-    bool lane_fast = true, off = true;              // off: all M rows outside the mask
+    bool uni = true;
+    unsigned inm = 0;
     f0 = 0; fS = 0;
 #pragma unroll
     for (int r = 0; r < M; ++r) {
         const unsigned f = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, ADI_LOAD_AUX);
         d[r] = buf_load_f64_once(rT, voff * 8u, (unsigned)r * st * 8u);
-        off = off && !(f & 1u);
-        if (r == 0) { f0 = f; lane_fast = lane_fast && ((f & ROW0) == ROW0); }
+        inm |= (f & 1u) << r;
+        if (r == 0) { f0 = f; uni = uni && ((f & ROW0) == ROW0); }
         else if (r == M - 1) fS = f;
-        else lane_fast = lane_fast && ((f & FULL) == FULL);
+        else uni = uni && ((f & FULL) == FULL);
     }
+    bool nodir = true;
     dirS = false;
     if (HAS_DIR) {
         const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void *)dmask_t, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int r = 0; r < M - 1; ++r)
-            lane_fast = lane_fast && (off || __builtin_amdgcn_raw_buffer_load_b8(rD, voff, (unsigned)r * st, 0) == 0);
-        dirS = !off && __builtin_amdgcn_raw_buffer_load_b8(rD, voff, (unsigned)(M - 1) * st, 0) != 0;
+            nodir = nodir && (inm == 0u || __builtin_amdgcn_raw_buffer_load_b8(rD, voff, (unsigned)r * st, 0) == 0);
+        dirS = inm != 0u && __builtin_amdgcn_raw_buffer_load_b8(rD, voff, (unsigned)(M - 1) * st, 0) != 0;
     }
-    return lane_fast || off;
+    Lm = 0;
+    if (uni) kind = nodir ? SEG_UNI : SEG_NONE;
+    else {
+        kind = classify_mixed<M>(inm, f0, g.lbit, Lm);
+        if (kind >= SEG_TAIL && !nodir) kind = SEG_NONE;
+    }
+    return kind != SEG_NONE;
 }
 
 // The same with the explicit stage folded in (FUSE kernels): d <- R0 = T + f*(Lx+Ly+Lz) of this thread's M rows.
@@ -909,11 +930,12 @@ __device__ __forceinline__ double row_bcast(double v, int r)
     }
 }
 
-template <int M, bool HAS_DIR>
+template <int M, bool HAS_DIR, bool MIXED = true>
 __device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict__ in, const uint8_t *__restrict__ flags_t,
                                                         const uint8_t *__restrict__ dmask_t, const LineGeom &g,
                                                         unsigned voff, int r0, int kk, long tbase, const Fuse &fz,
-                                                        double (&d)[M], unsigned &f0, unsigned &fS, bool &dirS)
+                                                        double (&d)[M], unsigned &f0, unsigned &fS, bool &dirS, int &kind,
+                                                        int &Lm)
 {
 #pragma clang fp contract(off)
     constexpr int LINES = 16;
@@ -943,15 +965,17 @@ __device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict
     const unsigned ve = R0 + (unsigned)(r0 + (int)(threadIdx.x & 15u)) * st8;
     const double eL = buf_load_f64(rT, ve - 8u, 0u);
     const double eR = buf_load_f64(rT, ve + LINES * 8u, 0u);
-    bool lane_fast = true, full = true, off = true;
+    bool uni = true, full = true;
+    unsigned inm = 0;                               // MIXED: bit r = row r in the mask; otherwise just "any row in the mask"
 #pragma unroll
     for (int r = 0; r < M; ++r) {
         full = full && (fb[r] == 0x7fu);
-        off = off && !(fb[r] & 1u);
-        if (r == 0) lane_fast = lane_fast && ((fb[r] & ROW0) == ROW0);
-        else if (r < M - 1) lane_fast = lane_fast && ((fb[r] & FULL) == FULL);
+        if (MIXED) inm |= (fb[r] & 1u) << r;
+        else inm |= fb[r];
+        if (r == 0) uni = uni && ((fb[r] & ROW0) == ROW0);
+        else if (r < M - 1) uni = uni && ((fb[r] & FULL) == FULL);
     }
-    lane_fast = lane_fast || off;                   // all rows outside the mask: identity rows, R0 = T
+    if (!MIXED) inm &= 1u;
     f0 = fb[0]; fS = fb[M - 1];
     const bool wave_full = __all(full);                     // every cell of this wave has its six neighbours
     // j-neighbour rows: a software pipeline D rows deep (they are L2 hits -- the tiles of the adjacent j-rows run next
@@ -992,14 +1016,22 @@ __device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    bool nodir = true;
     dirS = false;
     if (HAS_DIR) {
 #pragma unroll
         for (int r = 0; r < M - 1; ++r)
-            lane_fast = lane_fast && (off || (dmask_t + (size_t)r * g.stride)[voff] == 0);
-        dirS = !off && (dmask_t + (size_t)(M - 1) * g.stride)[voff] != 0;
+            nodir = nodir && (inm == 0u || (dmask_t + (size_t)r * g.stride)[voff] == 0);
+        dirS = inm != 0u && (dmask_t + (size_t)(M - 1) * g.stride)[voff] != 0;
     }
-    return lane_fast;
+    Lm = 0;
+    if (uni) kind = nodir ? SEG_UNI : SEG_NONE;
+    else if (!MIXED) kind = (inm == 0u) ? SEG_OFF : SEG_NONE;
+    else {
+        kind = classify_mixed<M>(inm, f0, g.lbit, Lm);     // rows outside the mask have R0 = T: identity rows
+        if (kind >= SEG_TAIL && !nodir) kind = SEG_NONE;
+    }
+    return kind != SEG_NONE;
 }
 
 // part 2: the two general rows of a uniform segment (row 0 and the separator)
@@ -1024,7 +1056,7 @@ __device__ __forceinline__ void fast_segment_ends(const double *__restrict__ coe
 }
 
 // FAST kernel (sparse packs): tiles whose every segment is uniform-interior (see k_sweep_contig_fast)
-template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false, bool MIXED = true>
 __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_fast(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
@@ -1052,6 +1084,7 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
     const long tbase = to * g.outer_stride + (long)ti * LINES;
     const unsigned voff = (unsigned)((long)r0 * g.stride + kk);
     const bool pad = r0 >= g.n;                    // this thread's segment lies beyond the end of the line
+    int kind = SEG_NONE, Lm = 0;                   // segment class (classify_mixed) and length of a mixed run
     bool lane_fast;
     if constexpr (FUSE) {
         // whole tiles only (block-uniform): anything else goes to the GENERAL kernel before a single load is issued
@@ -1061,19 +1094,23 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
         }
         // a padding segment (line with fewer than Lp segments) re-reads segment 0 -- valid addresses, values unused
         const int r0e = pad ? 0 : r0;
-        lane_fast = fast_segment_load_fused<M, HAS_DIR>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g,
-                                                        pad ? (unsigned)kk : voff, r0e, kk, tbase, fz, d, f0, fS, dirS) || pad;
+        lane_fast = fast_segment_load_fused<M, HAS_DIR, MIXED>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g,
+                                                               pad ? (unsigned)kk : voff, r0e, kk, tbase, fz, d, f0, fS, dirS,
+                                                               kind, Lm) || pad;
+        if (pad) kind = SEG_PAD;
     } else {
         // whole tiles whose rows fit 31-bit byte offsets take the buffer-addressed loader (block-uniform choice)
         const bool whole = kBufStrided && (ti + 1) * LINES <= g.n_inner && Lp * M == g.n &&
                            (long)g.n * g.stride * 8 < 0x7fffffffL;
         if (whole)
             lane_fast = fast_segment_load_buf<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, d,
-                                                          f0, fS, dirS);
+                                                          f0, fS, dirS, kind, Lm);
         else
             lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
-                                                      active, d, f0, fS, dirS);
+                                                      active, d, f0, fS, dirS, kind, Lm);
     }
+    if (pad) { f0 = 0; fS = 0; dirS = false; }       // (the fused loader showed a padding thread segment 0's flags)
+    if (!MIXED && kind >= SEG_TAIL) lane_fast = false;
     if (!__syncthreads_and(lane_fast)) {
         if (tid == 0) enqueue_unit(queue, (unsigned)tile);
         return;
@@ -1091,17 +1128,24 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
     Cond k;
     double kappa;
     condense_uniform<M>(U, a0, b0, d, k, kappa);
-    // a segment outside the mask (every flag has bit 0 clear; the only other way past the tile vote without the
-    // in-mask first row of a uniform segment): identity rows, x = in
-    const bool off = !pad && !(f0 & 1u);
+    const bool off = kind == SEG_OFF;              // a segment outside the mask: identity rows, x = in
     if (pad || off) {                              // identity block: nothing reaches the real segments
         k.gF = k.aF = k.cF = k.gL = k.aL = k.cL = 0.0;
         kappa = 0.0; aS = 0.0; bS = 1.0; cS = 0.0;
         if (pad) d[M - 1] = 0.0;
     }
+    double bmod = 1.0;
+    if constexpr (MIXED) {
+        if (kind >= SEG_TAIL)                      // the surface crosses the segment once (adi_core.hpp, mixed_*)
+            mixed_lane_condense<M, HAS_Q>(kind, Lm, U, s, coeff + base + (long)r0 * g.stride,
+                                          HAS_Q ? qf + base + (long)r0 * g.stride : qf, g.stride, a0, b0, d, bmod, k);
+    }
     double xL, xS;
     tile_separators(sm, tid, kk, sg, Lp, LINES, aS, bS, cS, d[M - 1], k, xL, xS);
-    if (!off) back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
+    if (kind == SEG_UNI || kind == SEG_PAD) back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
+    else if constexpr (MIXED) {
+        if (kind >= SEG_TAIL) mixed_lane_back_solve<M>(kind, Lm, U, bmod, a0, d, xL, xS);
+    }
     if (pad) return;                               // (after the last barrier)
     double *out_t = out + tbase;
     if (FUSE || (kBufStrided && (long)g.n * g.stride * 8 < 0x7fffffffL)) {
@@ -1235,6 +1279,7 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_condense_strid
     const long tbase = to * g.outer_stride + (long)ti * LINES;
     const unsigned voff = (unsigned)((long)r0 * g.stride + kk);
     const bool pad = r0 >= g.n;                    // this thread's segment lies beyond the end of the line
+    int kind = SEG_NONE, Lm = 0;                   // segment class (classify_mixed) and length of a mixed run
     bool lane_fast;
     if constexpr (FUSE) {
         // whole tiles only (block-uniform): anything else goes to the GENERAL kernel before a single load is issued
@@ -1245,18 +1290,21 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_condense_strid
         // a padding segment (line with fewer than Lp segments) re-reads segment 0 -- valid addresses, values unused
         const int r0e = pad ? 0 : r0;
         lane_fast = fast_segment_load_fused<M, HAS_DIR>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g,
-                                                        pad ? (unsigned)kk : voff, r0e, kk, tbase, fz, d, f0, fS, dirS) || pad;
+                                                        pad ? (unsigned)kk : voff, r0e, kk, tbase, fz, d, f0, fS, dirS, kind,
+                                                        Lm) || pad;
+        if (pad) kind = SEG_PAD;
     } else {
         // whole tiles whose rows fit 31-bit byte offsets take the buffer-addressed loader (block-uniform choice)
         const bool whole = kBufStrided && (ti + 1) * LINES <= g.n_inner && Lp * M == g.n &&
                            (long)g.n * g.stride * 8 < 0x7fffffffL;
         if (whole)
             lane_fast = fast_segment_load_buf<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, d,
-                                                          f0, fS, dirS);
+                                                          f0, fS, dirS, kind, Lm);
         else
             lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
-                                                      active, d, f0, fS, dirS);
+                                                      active, d, f0, fS, dirS, kind, Lm);
     }
+    if (pad) { f0 = 0; fS = 0; dirS = false; }       // (the fused loader showed a padding thread segment 0's flags)
     if (!__syncthreads_and(lane_fast)) {
         if (tid == 0) enqueue_unit(queue, (unsigned)tile);
         return;
@@ -1277,10 +1325,14 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_condense_strid
     if (pad) {                                     // finite values; tile_reduce_store ignores blocks >= n / M
         ki.gF = ki.aF = ki.cF = ki.gL = ki.aL = ki.cL = 0.0;
         aS = 0.0; bS = 1.0; cS = 0.0; d[M - 1] = 0.0;
-    } else if (!(f0 & 1u)) {                       // segment outside the mask: M identity rows
+    } else if (kind == SEG_OFF) {                  // segment outside the mask: M identity rows
         ki.gF = d[0]; ki.gL = d[M - 2];
         ki.aF = ki.cF = ki.aL = ki.cL = 0.0;
         aS = 0.0; bS = 1.0; cS = 0.0;
+    } else if (kind >= SEG_TAIL) {                 // the surface crosses the segment once
+        double bmod;
+        mixed_lane_condense<M, HAS_Q>(kind, Lm, U, s, coeff + base + (long)r0 * g.stride,
+                                      HAS_Q ? qf + base + (long)r0 * g.stride : qf, g.stride, a0, b0, d, bmod, ki);
     }
     const double ib = frcp(bS);
     Cond rowc;
@@ -2213,9 +2265,14 @@ static void launch_strided_fast(const StridedPlan &P, const double *in, const ui
                                 const LineGeom &g, const double *xlo, const double *xhi, SweepScal s, unsigned *queue,
                                 hipStream_t st, const Fuse &fz)
 {
-    hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE>), dim3((unsigned)P.ntiles_f),
-                       dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
-                       P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
+    if (FUSE && s.box)     // all-solid box (caller's hint): the build without TAIL / HEAD lanes, no spills
+        hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE, !FUSE>), dim3((unsigned)P.ntiles_f),
+                           dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
+                           P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
+    else
+        hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE, true>), dim3((unsigned)P.ntiles_f),
+                           dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
+                           P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
 }
 
 template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE>
@@ -2635,7 +2692,7 @@ int adi_axis0_dots_finish(int variant, const double *d_part, const double *d_wei
     const long nlines = (long)ny * nz;
     ADI_REQUIRE(line_begin >= 0 && line_end <= nlines && line_begin < line_end, "adi_axis0_dots_finish: bad line range");
     SweepScal s;
-    s.tg = theta * gam; s.dt = dt; s.Tinf = Tinf; s.sparse = 0;
+    s.tg = theta * gam; s.dt = dt; s.Tinf = Tinf; s.sparse = 0; s.box = 0;
     hipStream_t st = as_stream(stream);
     const long nsel = line_end - line_begin;
     const int nchunk = (nx + dots_ichunk(nx) - 1) / dots_ichunk(nx);
@@ -2695,7 +2752,8 @@ static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t 
     s.tg = theta * gam;
     s.dt = dt;
     s.Tinf = Tinf;
-    s.sparse = sparse ? 1 : 0;
+    s.sparse = (sparse & 1) ? 1 : 0;
+    s.box = (sparse & 2) ? 1 : 0;
     hipStream_t st = as_stream(stream);
     int rc;
     if (has_dir && has_q) rc = sweep_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, L, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st, fz);
@@ -2780,7 +2838,8 @@ static int condense_entry(int axis, int variant, const double *d_in, const uint8
     s.tg = theta * gam;
     s.dt = dt;
     s.Tinf = Tinf;
-    s.sparse = sparse ? 1 : 0;
+    s.sparse = (sparse & 1) ? 1 : 0;
+    s.box = (sparse & 2) ? 1 : 0;
     hipStream_t st = as_stream(stream);
     int rc;
     if (has_dir && has_q) rc = condense_dispatch<true, true>(axis, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, L, s, d_cond, d_work, work_bytes, st, fz);

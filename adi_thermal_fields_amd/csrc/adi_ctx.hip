@@ -41,6 +41,7 @@ struct adi_ctx {
     int cur;             // index of the current state buffer
     int variant;         // ADI_SWEEP_* chosen at build_coeffs time
     bool have_mask, have_packs, have_T;
+    bool all_solid;      // every cell in the mask: passed to adi_step as the box hint (bit 1 of `sparse`)
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     float last_ms;
@@ -155,6 +156,10 @@ int adi_ctx_set_mask(adi_ctx *c, const uint8_t *h_mask)
     int rc = adi_build_nbr_flags(c->mask, c->nx, c->ny, c->nz, c->sx, c->flags, c->stream);
     if (rc != ADI_OK) return rc;
     ADI_HIP_TRY(hipStreamSynchronize(c->stream));
+    bool all = true;
+    const size_t cells = (size_t)c->nx * c->ny * c->nz;
+    for (size_t i = 0; i < cells && all; ++i) all = h_mask[i] != 0;
+    c->all_solid = all;
     c->have_mask = true;
     c->have_packs = false;  // packs depend on the mask: rebuild before the next step
     return ADI_OK;
@@ -261,7 +266,7 @@ int adi_ctx_step(adi_ctx *c, double rho, double cp, double k, double dt, double 
     for (int s = 0; s < nsteps; ++s) {
         const int nxt = c->cur ^ 1;
         int rc = adi_step(c->T[c->cur], c->T[nxt], c->tmp[0], c->tmp[1], c->flags, c->coeff, c->dir_mask, c->dir_val,
-                          c->qflux, c->variant, 1, c->nx, c->ny, c->nz, c->sx, c->dx, rho, cp, k, dt, theta, Tinf, c->work,
+                          c->qflux, c->variant, 1 | (c->all_solid ? 2 : 0), c->nx, c->ny, c->nz, c->sx, c->dx, rho, cp, k, dt, theta, Tinf, c->work,
                           c->work_bytes, c->stream);
         if (rc != ADI_OK) return rc;
         c->cur = nxt;

@@ -153,6 +153,7 @@ class HipEngine:
         from . import _lib
         self.hip, self._lib, self.lib, self.check = hip, _lib, _lib.lib, _lib.check
         self.device = hip._device()
+        self.box_hint = 0          # 2: every cell of every slab is in the mask (SlabStepper.set_mask decides, collectively)
 
     def layout(self, nx, ny, nz, sx=None):
         return self.hip.Layout(nx, ny, nz, sx)
@@ -184,7 +185,7 @@ class HipEngine:
     def _args(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf):
         h = self.hip
         return (axis, variant, h._p(t_in), h._p(flags), h._p(pack[0]), h._p(pack[1]), h._p(pack[2]), h._p(pack[3]),
-                Li.nx, Li.ny, Li.nz, Li.sx, 1, theta, gam, dt, float(Tinf))   # packs come from adi_build_coeffs: sparse ok
+                Li.nx, Li.ny, Li.nz, Li.sx, 1 | self.box_hint, theta, gam, dt, float(Tinf))   # packs from adi_build_coeffs: sparse
 
     def _workspace(self, Li):
         """unit queue of the FAST/GENERAL kernel pair (sized for the largest box seen)"""
@@ -219,7 +220,7 @@ class HipEngine:
         tv = T_ext[i0:i0 + L.nx, j0:j0 + L.ny, :]
         vlo, vhi = h.valid_range(tv)
         return (variant, h._p(tv), vlo, vhi, h._p(flags), h._p(pack[0]), h._p(pack[1]), h._p(pack[2]), h._p(pack[3]),
-                L.nx, L.ny, L.nz, L.sx, 1, dx, dt, kappa, theta, float(Tinf))
+                L.nx, L.ny, L.nz, L.sx, 1 | self.box_hint, dx, dt, kappa, theta, float(Tinf))
 
     def sweep0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, t_out, xlo=None, xhi=None):
         h = self.hip
@@ -340,6 +341,11 @@ class SlabStepper:
         if self.rank < self.world - 1:
             d_mask[-1].copy_(hi)
         self.d_mask_ext = d_mask
+        if hasattr(E, 'box_hint'):                 # all-solid on every rank -> the kernels' leaner build (a hint only)
+            f = E.vec(1); f.fill_(1.0 if bool(mask_local.all()) else 0.0)
+            allf = E.vec(self.world)
+            self.comm.all_gather(allf, f)
+            E.box_hint = 2 if float(allf.min()) >= 1.0 else 0
         self.flags_ext = E.build_flags(L, d_mask)
 
         def ext(a, fill):
