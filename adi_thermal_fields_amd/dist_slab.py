@@ -255,6 +255,10 @@ class HipEngine:
                                                h._p(dd['cls']), h._p(dd['list']), h._stream()))
         return dd
 
+    def dots_nonuniform_fraction(self, dd):
+        """share of the lines adi_axis0_classify left to the per-line condensation (reads one int: synchronises)"""
+        return int(dd['list'][0].item()) / float(dd['cls'].numel())
+
     def explicit_dots(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin, i_end, dd):
         h = self.hip
         self.check(self.lib.adi_explicit_rhs_dots(h._p(T_ext), h._p(flags_ext), L.nx, L.ny, L.nz, L.sx, dx, dt, kappa,
@@ -434,6 +438,7 @@ class SlabStepper:
 
     # -- how the axis-0 interface system is solved ------------------------------------------------------
     DECAY_TOL = 1e-17      # |aL|, |cF| at or below this are dropped (they multiply values of the size of the data)
+    DOTS_MAX_NONUNIFORM = 0.05   # share of axis-0 lines that are not uniform above which pass A leaves the dot-product form
 
     def _chunk_ranges(self, nch):
         nch = nch if self.ny >= 8 * nch else 1
@@ -539,8 +544,17 @@ class SlabStepper:
         self.comm.all_gather(allf, flag)
         plan['dots'] = bool(float(allf.min()) >= 1.0)
         if plan['dots']:
-            plan['fused'] = plan['keep_r0'] = False
-            plan['dd'] = E.dots_setup(self.Lint, self.flags_int, self.packs_int[0][1], prm.theta, gam)
+            # the dot products serve lines that are uniform along the axis; the others are condensed one thread per
+            # line from R0.  On a curved solid most lines are of the second kind: there the tiled pass-A kernels (which
+            # take surface segments, section 3.2b of DESIGN.md) are the better pass A.  Collective decision.
+            dd = E.dots_setup(self.Lint, self.flags_int, self.packs_int[0][1], prm.theta, gam)
+            flag.fill_(float(E.dots_nonuniform_fraction(dd)) if hasattr(E, 'dots_nonuniform_fraction') else 0.0)
+            self.comm.all_gather(allf, flag)
+            if float(allf.max()) > self.DOTS_MAX_NONUNIFORM:
+                plan['dots'] = False
+            else:
+                plan['fused'] = plan['keep_r0'] = False
+                plan['dd'] = dd
         self._a0_key, self._a0 = key, plan
         self.axis0_mode = plan['mode']
         return plan

@@ -38,6 +38,8 @@ def _run_slabs(c, world, sizes, nsteps, opts=None, modes=None):
             st._allow_fused = bool(o.get('allow_fused', True))
             st._allow_dots = bool(o.get('allow_dots', True))
             st._keep_r0 = bool(o.get('keep_r0', True))
+            if 'dots_max' in o:
+                st.DOTS_MAX_NONUNIFORM = o['dots_max']
             T = hip.to_device(np.ascontiguousarray(c['T0'][i0:i1]))
             for s in range(nsteps):
                 T = st.step(T, prefetch_halo=bool(o.get('prefetch', False)) and s + 1 < nsteps)
@@ -60,12 +62,12 @@ def _run_slabs(c, world, sizes, nsteps, opts=None, modes=None):
 
 # pass-A forms: dot products inside the explicit stage (default), fused strided pass A (with / without R0 kept for
 # pass B), explicit stage + pass A as separate kernels
-PASS_A = {'dots': {}, 'fused': dict(allow_dots=False), 'fused_recompute': dict(allow_dots=False, keep_r0=False),
+PASS_A = {'dots': dict(dots_max=1.0), 'auto': {}, 'fused': dict(allow_dots=False), 'fused_recompute': dict(allow_dots=False, keep_r0=False),
           'separate': dict(allow_dots=False, allow_fused=False)}
 
 
 @pytest.mark.parametrize('world,case_name,form', [(2, 'holes_mixed', 'dots'), (2, 'holes_mixed', 'fused'),
-                                                  (2, 'holes_mixed', 'separate'), (3, 'kat2', 'dots'),
+                                                  (2, 'holes_mixed', 'separate'), (2, 'holes_mixed', 'auto'), (3, 'kat2', 'dots'),
                                                   (3, 'kat2', 'fused_recompute'), (4, 'long_line_70', 'dots'),
                                                   (4, 'long_line_70', 'fused'), (3, 'slab_chunks', 'dots'),
                                                   (3, 'slab_chunks', 'separate'), (2, 'dirichlet_only_gamma07', 'dots')])
