@@ -162,3 +162,22 @@ def test_slabs_solid_512_lines_dots_all_ranks():
         modes = set()
         got = _run_slabs(c, 3, [128, 128, 128], 2, o, modes)
         assert rel_linf(got, want) <= 1e-12, (o, modes, rel_linf(got, want))
+
+
+@pytest.mark.parametrize('form', ['separate', 'fused', 'dots', 'auto'])
+def test_slabs_512_planes_per_rank_curved_solid(form):
+    """2 slabs of 512 planes (the bench's slab thickness: 32-row wide tiling of the unfused pass A, 16-row tiles of the
+    fused one) through an ellipsoid: surface segments (TAIL / HEAD) in every pass-A form, against the one-domain step"""
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    rng = np.random.default_rng(12)
+    shape = (1024, 6, 32)
+    g = np.meshgrid(*[(np.arange(n) + 0.5) / n - 0.5 for n in shape], indexing='ij')
+    mask = (g[0] / 0.47) ** 2 + (g[1] / 0.49) ** 2 + (g[2] / 0.48) ** 2 <= 1.0
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,
+             T0=rng.uniform(20.0, 1200.0, shape), dir_mask=None, dir_value=None, neumann={'x-': 1e5},
+             robin_h=250.0, Tinf=20.0, theta=0.5, dt=150.0 * dx * dx / alpha, nsteps=2, births=None)
+    want = run_cart_case(hip, c)['T_final']
+    got = _run_slabs(c, 2, [512, 512], 2, dict(PASS_A[form], prefetch=True))
+    assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
