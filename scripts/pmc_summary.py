@@ -28,9 +28,16 @@ def pick(sub):
     tot = [v['hbm_bytes'] for k, v in kern.items() if sub in k and 'true, true>' not in k]
     return sum(tot) if tot else None
 def pick_fused(sub, fused):
-    # FUSE is the last template argument of the strided kernels: <M, HAS_DIR, HAS_Q, FUSE>
-    tot = [v['hbm_bytes'] for k, v in kern.items() if sub in k and 'true, true,' not in k
-           and k.rstrip('>').endswith('true' if fused else 'false')]
+    # template arguments of the strided kernels: <M, HAS_DIR, HAS_Q, FUSE[, MIXED]>
+    tot = []
+    for k, v in kern.items():
+        if sub not in k or '<' not in k:
+            continue
+        args = [a.strip() for a in k[k.index('<') + 1:k.rindex('>')].split(',')]
+        if len(args) < 4 or (args[1] == 'true' and args[2] == 'true'):     # dense general-pack measurements: not a stage
+            continue
+        if (args[3] == 'true') == fused:
+            tot.append(v['hbm_bytes'])
     return sum(tot) if tot else None
 out = dict(note='HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of wide reads); '
                 'sweeps = FAST kernel + GENERAL kernel on the queued units; keys are bench.py stage names',
