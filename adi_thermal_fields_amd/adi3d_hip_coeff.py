@@ -207,6 +207,8 @@ class Grid3D:
 
     @property
     def mask(self):
+        if self._mask is None and self._d_mask is not None:       # device-side mask (set_mask_device): download on demand
+            self._mask = self._d_mask.cpu().contiguous().numpy().astype(np.bool_)
         return self._mask
 
     @mask.setter
@@ -218,9 +220,27 @@ class Grid3D:
         self._mask = m                                   # rebinding keeps the caller's object, as in the reference
         self.sync_mask()
 
+    def set_mask_device(self, d_mask):
+        """`grid.mask = ...` for a mask that already lives on the device (uint8 tensor in the grid's layout, e.g.
+        updated in place by a birth): no host round trip; the neighbour flags are rebuilt from it and the host copy is
+        downloaded only if somebody reads `grid.mask`.  The device loop of waam.run_layer_birth uses this."""
+        assert self.layout.is_native(d_mask) and d_mask.dtype == torch.uint8
+        self._d_mask = d_mask
+        self._mask = None
+        self._device_mask = True
+        self._d_flags = self.layout.empty(torch.uint8, zero=True)
+        check(lib.adi_build_nbr_flags(_p(self._d_mask), self.nx, self.ny, self.nz, self.sx, _p(self._d_flags),
+                                      _stream()))
+        self.mask_version += 1
+        self.all_solid = bool((d_mask != 0).all())
+        return self._d_mask
+
     def sync_mask(self):
         """(Re)upload the host mask and rebuild its neighbour-flags digest; called on assignment and by
-        precompute_coeff_packs_unified."""
+        precompute_coeff_packs_unified.  A device-side mask (set_mask_device) is authoritative as it is."""
+        if getattr(self, '_device_mask', False) and self._mask is None:
+            return self._d_mask
+        self._device_mask = False
         self._d_mask = self.layout.to_layout(self._mask, torch.uint8)
         self._d_flags = self.layout.empty(torch.uint8, zero=True)
         check(lib.adi_build_nbr_flags(_p(self._d_mask), self.nx, self.ny, self.nz, self.sx, _p(self._d_flags),

@@ -89,7 +89,7 @@ def _birth(backend, T, grid, newborn, Ts):
 
 
 def run_layer_birth(backend, mask_full, dx, mat_args, h, Tinf, Ts, theta, cfl, layers, times_birth, times_out,
-                    on_frame=None, device_resident=True):
+                    on_frame=None, device_resident=True, device_loop=True):
     """The event loop of waam_from_stl_v7_mm.py:515-550.  Returns (T_final as NumPy, number of ADI steps)."""
     nx, ny, nz = mask_full.shape
     mask_act = np.zeros_like(mask_full, dtype=bool)
@@ -122,30 +122,54 @@ def run_layer_birth(backend, mask_full, dx, mat_args, h, Tinf, Ts, theta, cfl, l
                 T = _step(backend, T, grid, mat, params, packs, Tinf)
         nsteps += nsub
 
+    # device loop: the full mask and the active mask live in HBM, a birth is three small tensor
+    # operations on the layer's planes plus the flags / pack rebuild kernels -- nothing crosses PCIe between output times
+    dev_loop = device_loop and device_resident and hasattr(grid, 'set_mask_device') and hasattr(T, 'fill_where')
+    if dev_loop:
+        import torch
+        d_full = grid.layout.to_layout(mask_full, torch.uint8)
+        d_act = grid.layout.empty(torch.uint8, zero=True)
+    n_active = 0
+
+    def host_mask():
+        return d_act.cpu().contiguous().numpy().astype(bool) if dev_loop else mask_act.copy()
+
     events = sorted(set(list(times_out) + list(times_birth)))
     for te in events:
         while next_birth < len(times_birth) and times_birth[next_birth] <= te + 1e-15:
             t_b = times_birth[next_birth]
             seg = max(0.0, t_b - t_now)
-            if seg > 1e-15 and mask_act.any():       # no ADI steps while nothing is active (:524)
+            if seg > 1e-15 and n_active > 0:         # no ADI steps while nothing is active (:524)
                 advance(seg)
             t_now = t_b
             ks, ke = layers[next_birth]
-            born = np.zeros_like(mask_full, dtype=bool)
-            born[:, :, ks:ke + 1] = mask_full[:, :, ks:ke + 1]
-            newborn = born & (~mask_act)
-            if newborn.any():
-                T = _birth(backend, T, grid, newborn, Ts)
-            mask_act |= born
-            grid.mask = mask_act                       # :494-495
+            if dev_loop:
+                born = d_full[:, :, ks:ke + 1]
+                act = d_act[:, :, ks:ke + 1]
+                newborn = (born != 0) & (act == 0)
+                nb = int(newborn.sum())
+                if nb:
+                    T.t[:, :, ks:ke + 1][newborn] = Ts          # T[newborn] = Ts (:489-493)
+                act |= born
+                n_active += nb
+                grid.set_mask_device(d_act)                     # :494-495 without the host round trip
+            else:
+                born = np.zeros_like(mask_full, dtype=bool)
+                born[:, :, ks:ke + 1] = mask_full[:, :, ks:ke + 1]
+                newborn = born & (~mask_act)
+                if newborn.any():
+                    T = _birth(backend, T, grid, newborn, Ts)
+                mask_act |= born
+                n_active = int(mask_act.sum())
+                grid.mask = mask_act                       # :494-495
             packs = build_packs()                      # :534
             next_birth += 1
         seg = max(0.0, te - t_now)
-        if seg > 1e-15 and mask_act.any():
+        if seg > 1e-15 and n_active > 0:
             advance(seg)
         t_now = te
         if on_frame is not None and any(abs(te - to) <= 1e-12 for to in times_out):
-            on_frame(t_now, np.asarray(T), mask_act.copy())
+            on_frame(t_now, np.asarray(T), host_mask())
     return np.asarray(T), nsteps
 
 
