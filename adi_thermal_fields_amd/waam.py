@@ -216,6 +216,10 @@ def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, 
     robin = {f: h for f in ('x-', 'x+', 'y-', 'y+', 'z-', 'z+')}
     st = dist_slab.SlabStepper(mask_act[i0:i1], dx, mat, params, Tinf, robin_h=robin, comm=comm, engine=engine)
     T = np.full((i1 - i0, ny, nz), float(Tinf), dtype=np.float64)
+    on_device = getattr(st.engine.device, 'type', 'cpu') == 'cuda'
+    if on_device:                                   # the slab's field stays in HBM: step() hands back device tensors
+        import torch
+        T = torch.from_numpy(T).to(st.engine.device)
     nsteps, next_birth, t_now = 0, 0, 0.0
 
     def advance(seg):
@@ -239,9 +243,12 @@ def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, 
             born[:, :, ks:ke + 1] = mask_full[:, :, ks:ke + 1]
             newborn = (born & (~mask_act))[i0:i1]
             if newborn.any():
-                Tl = np.array(st.local_numpy(T))
-                Tl[newborn] = Ts
-                T = Tl
+                if on_device:
+                    T[torch.from_numpy(newborn).to(T.device)] = Ts      # in place (the last sub-step sent no halo ahead)
+                else:
+                    Tl = np.array(st.local_numpy(T))
+                    Tl[newborn] = Ts
+                    T = Tl
             mask_act |= born
             st.set_mask(mask_act[i0:i1])
             next_birth += 1
