@@ -36,7 +36,7 @@ import threading
 import numpy as np
 import torch
 
-__all__ = ['SlabStepper', 'TorchDistComm', 'LocalComm', 'LoopbackComm', 'HipEngine', 'split_planes']
+__all__ = ['SlabStepper', 'TorchDistComm', 'LocalComm', 'LoopbackComm', 'SelfLoopDistComm', 'HipEngine', 'split_planes']
 
 
 def split_planes(nx, world):
@@ -142,6 +142,39 @@ class LoopbackComm:
 
     def all_gather(self, out, inp):
         out.view(self.world, -1).copy_(inp.view(1, -1).expand(self.world, -1))
+
+
+class SelfLoopDistComm(TorchDistComm):
+    """Rehearsal on ONE GPU over the REAL transport: a single-rank RCCL process group in which this rank plays rank
+    `rank` of `world` and both its neighbours are itself (RCCL accepts batched send/recv to self).  Same data movement as
+    LoopbackComm, but through torch.distributed P2P on the side stream, so the stream / event ordering of SlabStepper is
+    exercised exactly as in a multi-GPU run (tests/test_dist_slab_gpu.py, bench.py --rehearse-world W --force-dist)."""
+
+    def __init__(self, world, rank, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        assert dist.get_world_size(group) == 1
+        self.me = dist.get_rank(group)
+        self.rank, self.world = rank, world
+
+    def exchange_planes(self, send_lo, send_hi, recv_lo, recv_hi):
+        dist, ops = self.dist, []
+        # sends and receives to one peer match in order: what goes up (send_hi) must land in recv_lo, and vice versa
+        if self.rank > 0 and self.rank < self.world - 1:
+            ops = [dist.P2POp(dist.isend, send_hi, self.me, self.group), dist.P2POp(dist.irecv, recv_lo, self.me, self.group),
+                   dist.P2POp(dist.isend, send_lo, self.me, self.group), dist.P2POp(dist.irecv, recv_hi, self.me, self.group)]
+        elif self.rank > 0:
+            ops = [dist.P2POp(dist.isend, send_hi, self.me, self.group), dist.P2POp(dist.irecv, recv_lo, self.me, self.group)]
+        elif self.rank < self.world - 1:
+            ops = [dist.P2POp(dist.isend, send_lo, self.me, self.group), dist.P2POp(dist.irecv, recv_hi, self.me, self.group)]
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+
+    def all_gather(self, out, inp):
+        one = torch.empty_like(inp)
+        self.dist.all_gather_into_tensor(one, inp, group=self.group)          # the real collective, world size 1
+        out.view(self.world, -1).copy_(one.view(1, -1).expand(self.world, -1))
 
 
 # ------------------------------------------------------------------------------------------ engine
@@ -318,6 +351,7 @@ class SlabStepper:
         self.fused = False
         self._keep_r0 = True                       # False: pass B re-evaluates the explicit stage instead of reading R0
         self._allow_dots = True                    # False: pass A as its own kernel (reads the slab a second time)
+        self._send_g_only = True                   # False: every step exchanges the matrix parts of the interface too
         self._comm_stream, self._use_streams = None, False
         self._halo_ready, self._halo_event = None, None
         self._gam = 0.0
@@ -597,8 +631,15 @@ class SlabStepper:
             self.comm.all_gather(b['cond_all'], b['cond'])
         else:
             n = b['nl']
-            self.comm.exchange_planes(b['cond_lo'].view(6, n)[0:2], b['cond_hi'].view(6, n)[3:6],
-                                      b['prev_hi'].view(3, n), b['next_lo'].view(2, n))
+            if b.get('matrix_sent') and self._send_g_only:
+                # aF and (aL, cL) are entries of the condensed MATRIX: they depend on dt, theta and the mask only (this
+                # plan), so after the first exchange only the right-hand-side parts gF / gL travel (2 of 5 arrays)
+                self.comm.exchange_planes(b['cond_lo'].view(6, n)[0:1], b['cond_hi'].view(6, n)[3:4],
+                                          b['prev_hi'].view(3, n)[0:1], b['next_lo'].view(2, n)[0:1])
+            else:
+                self.comm.exchange_planes(b['cond_lo'].view(6, n)[0:2], b['cond_hi'].view(6, n)[3:6],
+                                          b['prev_hi'].view(3, n), b['next_lo'].view(2, n))
+                b['matrix_sent'] = True
 
     def _solve_and_sweep(self, plan, Ai, Bi, b):
         """interface values of one chunk of lines, then pass B: the local sweep with them injected"""
@@ -621,21 +662,22 @@ class SlabStepper:
             E.sweep(0, v, b['Lb'], cut(Ai), cut(fl), tuple(cut(t) for t in pk), prm.theta, self._gam, prm.dt, self.Tinf,
                     cut(Bi), b['xlo'], b['xhi'])
 
-    def _axis0_pipeline(self, plan, Ai, Bi, condensed=False):
+    def _axis0_pipeline(self, plan, Ai, Bi, condensed=False, before_chunk=None):
         """pass A, exchange, interface solve and pass B over the chunks of lines; with RCCL the exchange of chunk c
-        runs on a second stream while chunk c+1 is condensed and chunk c-1 is solved."""
+        runs on a second stream while chunk c+1 is condensed and chunk c-1 is solved.  before_chunk(b): work that has to
+        precede pass A of chunk b on the main stream (the explicit stage of its rows in the dot-product form)."""
         bufs = plan['chunks']
         use_streams = self._use_streams
         main = torch.cuda.current_stream() if use_streams else None
-        ev_a, ev_x = [], []
+        ev_x = []
         for b in bufs:
+            if before_chunk is not None:
+                before_chunk(b)
             if not condensed:
                 self._condense_windows(plan, Ai, b)
             if use_streams:
-                e = torch.cuda.Event(); e.record(main); ev_a.append(e)
-        if use_streams:
-            with torch.cuda.stream(self._comm_stream):
-                for b, e in zip(bufs, ev_a):
+                e = torch.cuda.Event(); e.record(main)
+                with torch.cuda.stream(self._comm_stream):     # issued now: it overlaps the next chunk's main-stream work
                     self._comm_stream.wait_event(e)
                     self._exchange_interface(plan, b)
                     e2 = torch.cuda.Event(); e2.record(self._comm_stream); ev_x.append(e2)
@@ -739,6 +781,8 @@ class SlabStepper:
             # one pass over the slab: R0 and, per line, the two dot products of pass A (halos must have landed)
             if halo_ev is not None and streams:
                 main.wait_event(halo_ev)
+            # (running the explicit stage chunk by chunk of lines, so that a chunk's interface exchange travels behind
+            # the next chunk's explicit stage, was measured over the RCCL self-loop: no gain, 1.99 -> 2.02 ms)
             E.explicit_dots(self.Lext, Text, self.flags_ext, self.dx, prm.dt, kappa, prm.theta, A, 1, nl + 1, plan['dd'])
             mark()
             ev_x = self._axis0_pipeline(plan, Ai, Bi)

@@ -38,6 +38,9 @@ def parse():
     ap.add_argument('--n', type=int, default=512, help='cells per axis per GPU')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-n', type=int, default=256, help='edge of the bounded CPU-baseline sample')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='one GPU only: run the slab code path over a real single-rank RCCL process group (checks the '
+                         'torch.distributed plumbing: init, all_gather, all_reduce, barrier); marked in the JSON line')
     ap.add_argument('--rehearse-world', type=int, default=0,
                     help='one GPU only: run the code path of a middle rank of a W-GPU job with a loopback communicator '
                          '(no wire time); the line is marked "rehearsal" and is not a measurement of W GPUs')
@@ -76,7 +79,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     rehearse = a.rehearse_world if (a.rehearse_world > 1 and world == 1 and a.gpus == 1) else 0
-    multi = world > 1 or rehearse > 1          # the slab code path
+    force_dist = a.force_dist and world == 1
+    multi = world > 1 or rehearse > 1 or force_dist   # the slab code path
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if a.gpus > 1 and world == 1:
         print('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % a.gpus,
@@ -86,9 +90,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or force_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if force_dist:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     import adi_thermal_fields_amd.adi3d_hip_coeff as adi
     from adi_thermal_fields_amd import _lib
@@ -103,7 +111,7 @@ def main():
     T0 = torch.rand((n, n, n), dtype=torch.float64, device=dev, generator=gen) * 980.0 + 20.0
 
     stage_names = ['explicit', 'sweep_axis0', 'sweep_axis1', 'sweep_axis2_contig']
-    if world == 1 and not rehearse:
+    if not multi:
         grid = adi.Grid3D(n, n, n, dx, np.ones((n, n, n), bool))
         packs = adi.precompute_coeff_packs_unified(grid, mat, robin_h=500.0)
         T = adi.DeviceField(T0)
@@ -112,7 +120,9 @@ def main():
         variant = packs[0].variant
     else:
         from adi_thermal_fields_amd import dist_slab
-        comm = dist_slab.LoopbackComm(rehearse, rehearse // 2) if rehearse else None
+        comm = None
+        if rehearse:      # a middle rank of `rehearse`: loopback copies, or (--force-dist) RCCL send/recv to itself
+            comm = (dist_slab.SelfLoopDistComm if force_dist else dist_slab.LoopbackComm)(rehearse, rehearse // 2)
         stepper = dist_slab.SlabStepper.from_local(T0, np.ones((n, n, n), bool), dx, mat, prm, Tinf,
                                                    robin_h=500.0, comm=comm)
         T = adi.DeviceField(T0)
@@ -120,7 +130,7 @@ def main():
         overlap_err, overlap_on = stepper.self_check(T)     # pipeline on the second stream vs plain ordering
 
     def sync():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -140,7 +150,7 @@ def main():
     sync()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = elapsed.item()
     assert bool(torch.isfinite(T.t).all().item())
@@ -206,8 +216,10 @@ def main():
         step_achieved_gbs=round(sum(bytes_per_cell.values()) * N / (ms_per_step * 1e-3) / 1e9, 1),
         **({'comm_overlap': dict(enabled=overlap_on, selfcheck_rel_diff=overlap_err,
                                  axis0_interface=stepper.axis0_mode,
-                                 pass_a=('dots_in_explicit' if stepper._a0.get('dots') else
-                                         ('fused' if stepper._a0.get('fused') else 'separate')))} if multi else {}),
+                                 pass_a=('dots_in_explicit' if (stepper._a0 or {}).get('dots') else
+                                         ('fused' if (stepper._a0 or {}).get('fused') else 'separate')))} if multi else {}),
+        **({'force_dist': 'slab code path over a single-rank RCCL process group' + (': halo / interface exchanges are RCCL '
+                           'send/recv to self on the side stream' if rehearse else ' (plumbing check)')} if force_dist else {}),
         **({'rehearsal': 'ONE GPU running the code path of rank %d of %d with a loopback communicator: per-rank compute '
                          'time without wire time, not a %d-GPU measurement' % (rehearse // 2, rehearse, rehearse)}
            if rehearse else {}),
@@ -224,12 +236,12 @@ def main():
                                           achieved=x['achieved_gbs'], peak=HBM_PEAK_GBS, unit='GB/s', frac=x['frac'],
                                           target_frac=0.60,
                                           lean_sparse_variant_in_step=kernels.get('sweep_axis2_contig'))
-    if world == 1 and not rehearse and not a.no_cpu:
+    if not multi and not a.no_cpu:
         st, mt = cpu_baseline(a.cpu_n)
         line['cpu_baseline'] = st
         line['cpu_baseline_all_cores'] = mt
     print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

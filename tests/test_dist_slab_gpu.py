@@ -181,3 +181,40 @@ def test_slabs_512_planes_per_rank_curved_solid(form):
     want = run_cart_case(hip, c)['T_final']
     got = _run_slabs(c, 2, [512, 512], 2, dict(PASS_A[form], prefetch=True))
     assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
+
+
+def test_slab_step_over_real_rccl_self_loop():
+    """the stepper of a middle rank over torch.distributed P2P (single-rank RCCL group, send/recv to self on the side
+    stream, events, prefetched halos) == the same rank over in-process loopback copies, bit for bit, in every pass-A form"""
+    import os
+    import torch
+    import torch.distributed as dist
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from adi_thermal_fields_amd import dist_slab
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        rng = np.random.default_rng(21)
+        shape = (128, 24, 64)
+        g = np.meshgrid(*[(np.arange(n) + 0.5) / n - 0.5 for n in shape], indexing='ij')
+        mask = (g[1] / 0.45) ** 2 + (g[2] / 0.48) ** 2 <= 1.0            # a cylinder along the sharded axis
+        dx = 1e-3
+        alpha = 54.0 / (7800.0 * 490.0)
+        T0 = rng.uniform(20.0, 900.0, shape)
+        for cfl, opts in ((150.0, {}), (150.0, dict(allow_dots=False)), (0.05, {}), (300.0, dict(force_exact=True))):
+            outs = []
+            for comm in (dist_slab.LoopbackComm(4, 1), dist_slab.SelfLoopDistComm(4, 1)):
+                st = dist_slab.SlabStepper(mask, dx, hip.Material(7800.0, 490.0, 54.0), hip.Params(cfl * dx * dx / alpha, 0.5),
+                                           20.0, robin_h=300.0, comm=comm)
+                st._allow_dots = opts.get('allow_dots', True); st._force_exact = opts.get('force_exact', False)
+                T = hip.to_device(T0)
+                for s in range(4):
+                    T = st.step(T, prefetch_halo=(s < 3))
+                torch.cuda.synchronize()
+                outs.append((T.get(), st.axis0_mode))
+            assert outs[0][1] == outs[1][1]
+            assert np.array_equal(outs[0][0], outs[1][0]), (cfl, opts, outs[0][1])
+    finally:
+        dist.destroy_process_group()
