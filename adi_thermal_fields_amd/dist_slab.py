@@ -472,12 +472,19 @@ class SlabStepper:
 
     # -- how the axis-0 interface system is solved ------------------------------------------------------
     DECAY_TOL = 1e-17      # |aL|, |cF| at or below this are dropped (they multiply values of the size of the data)
+    SLAB_CHUNK_EDGES = None      # e.g. (0.125, 0.5): cumulative line fractions of the 'slab' pipeline's chunks (None: halves)
     DOTS_MAX_NONUNIFORM = 0.05   # share of axis-0 lines that are not uniform above which pass A leaves the dot-product form
 
-    def _chunk_ranges(self, nch):
-        nch = nch if self.ny >= 8 * nch else 1
-        edges = [round(i * self.ny / nch) for i in range(nch + 1)]
-        return [(edges[i], edges[i + 1]) for i in range(nch) if edges[i + 1] > edges[i]]
+    def _chunk_ranges(self, nch, fractions=None):
+        """chunks of lines (ranges of j) of the axis-0 pipeline.  fractions: cumulative edges in (0, 1), e.g. a small
+        first chunk whose exchange is the only exposed one, each later exchange hiding behind the previous chunk's pass B"""
+        if fractions is not None and self.ny >= 64:
+            edges = [0] + [int(round(f * self.ny / 2.0)) * 2 for f in fractions] + [self.ny]
+        else:
+            nch = nch if self.ny >= 8 * nch else 1
+            edges = [round(i * self.ny / nch) for i in range(nch + 1)]
+        edges = sorted(set(edges))
+        return [(edges[i], edges[i + 1]) for i in range(len(edges) - 1) if edges[i + 1] > edges[i]]
 
     def _streams(self):
         E = self.engine
@@ -542,26 +549,6 @@ class SlabStepper:
             plan = None
         if plan is None:
             plan = dict(mode='exact', K=self.nxl)
-            ranges = self._chunk_ranges(4)
-        else:
-            # a window's exchange hides behind the explicit stage of the middle planes; a whole-slab condensation
-            # is pipelined over chunks of lines instead
-            ranges = self._chunk_ranges(1 if plan['mode'] == 'window' else 2)
-        bufs = []
-        for j0, j1 in ranges:
-            n = (j1 - j0) * self.nz
-            Lc = E.layout(plan['K'], j1 - j0, self.nz, self.Lint.sx)
-            Lb = E.layout(self.nxl, j1 - j0, self.nz, self.Lint.sx)
-            b = dict(j0=j0, j1=j1, nl=n, Lc=Lc, Lb=Lb, xlo=E.vec(n), xhi=E.vec(n))
-            if plan['mode'] == 'exact':
-                b.update(cond=E.vec(6 * n), cond_all=E.vec(6 * n * self.world))
-            else:
-                b['cond_hi'] = E.vec(6 * n)
-                b['cond_lo'] = E.vec(6 * n) if plan['mode'] == 'window' else b['cond_hi']
-                b['prev_hi'] = E.vec(3 * n)        # (gL, aL, cL) of the slab below
-                b['next_lo'] = E.vec(2 * n)        # (gF, aF) of the slab above
-            bufs.append(b)
-        plan['chunks'] = bufs
         plan['fused'] = self._fused_supported(plan['K'])     # the same on every rank (it depends on sizes only...
         if self.world > 1:                                   # ...but slabs may differ by two planes: make it collective)
             flag.fill_(1.0 if plan['fused'] else 0.0)
@@ -589,6 +576,31 @@ class SlabStepper:
             else:
                 plan['fused'] = plan['keep_r0'] = False
                 plan['dd'] = dd
+        # chunks of lines of the axis-0 pipeline.  Tiled pass A: the exchange of a chunk hides behind pass A of the next
+        # (2 chunks, 4 for the all-gather form).  Dot-product pass A has no pass-A kernel to hide behind and every extra
+        # exchange costs its fixed latency: ONE chunk (RCCL self-loop rehearsal at 512^3: 2.06 ms with two halves, 1.97 with
+        # one chunk; finer first chunks were slower still).  A window's exchange hides behind the middle planes' explicit stage.
+        if plan['dots'] or plan['mode'] == 'window':
+            ranges = self._chunk_ranges(1)
+        elif plan['mode'] == 'exact':
+            ranges = self._chunk_ranges(4)
+        else:
+            ranges = self._chunk_ranges(2, self.SLAB_CHUNK_EDGES)
+        bufs = []
+        for j0, j1 in ranges:
+            n = (j1 - j0) * self.nz
+            Lc = E.layout(plan['K'], j1 - j0, self.nz, self.Lint.sx)
+            Lb = E.layout(self.nxl, j1 - j0, self.nz, self.Lint.sx)
+            b = dict(j0=j0, j1=j1, nl=n, Lc=Lc, Lb=Lb, xlo=E.vec(n), xhi=E.vec(n))
+            if plan['mode'] == 'exact':
+                b.update(cond=E.vec(6 * n), cond_all=E.vec(6 * n * self.world))
+            else:
+                b['cond_hi'] = E.vec(6 * n)
+                b['cond_lo'] = E.vec(6 * n) if plan['mode'] == 'window' else b['cond_hi']
+                b['prev_hi'] = E.vec(3 * n)        # (gL, aL, cL) of the slab below
+                b['next_lo'] = E.vec(2 * n)        # (gF, aF) of the slab above
+            bufs.append(b)
+        plan['chunks'] = bufs
         self._a0_key, self._a0 = key, plan
         self.axis0_mode = plan['mode']
         return plan

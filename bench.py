@@ -125,6 +125,8 @@ def main():
             comm = (dist_slab.SelfLoopDistComm if force_dist else dist_slab.LoopbackComm)(rehearse, rehearse // 2)
         stepper = dist_slab.SlabStepper.from_local(T0, np.ones((n, n, n), bool), dx, mat, prm, Tinf,
                                                    robin_h=500.0, comm=comm)
+        if os.environ.get('ADI_SLAB_CHUNK_EDGES'):        # tuning knob, e.g. "0.125,0.5"
+            stepper.SLAB_CHUNK_EDGES = tuple(float(x) for x in os.environ['ADI_SLAB_CHUNK_EDGES'].split(','))
         T = adi.DeviceField(T0)
         variant = stepper.variant
         overlap_err, overlap_on = stepper.self_check(T)     # pipeline on the second stream vs plain ordering
