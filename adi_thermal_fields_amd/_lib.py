@@ -66,8 +66,9 @@ SIGNATURES = {
     'adi_axis0_dots_workspace': (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     'adi_axis0_dots_setup': (c_int, [c_int, c_double, c_double, c_void_p, c_void_p]),
     'adi_axis0_classify': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
+    'adi_axis0_dots_ichunk': (c_int, [c_int]),
     'adi_explicit_rhs_dots': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_double, c_double, c_double,
-                                      c_double, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                                      c_double, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'adi_axis0_dots_finish': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_double, c_double,
                                       c_double, c_double, c_long, c_long, c_void_p, c_void_p]),

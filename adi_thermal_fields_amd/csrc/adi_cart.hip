@@ -1712,7 +1712,7 @@ __global__ __launch_bounds__(256) void k_explicit_v5(const double *__restrict__ 
                                                      double *__restrict__ R0, Lay L, double invdx2, double f,
                                                      int jslab, int ktiles, int ichunk, long ntiles, int i_begin,
                                                      int i_end, const double *__restrict__ wu = nullptr,
-                                                     double *__restrict__ part = nullptr)
+                                                     double *__restrict__ part = nullptr, int i_org = 0, int n_line = 0)
 {
 #pragma clang fp contract(off)
     const int nx = L.nx, ny = L.ny, nz = L.nz;
@@ -1779,12 +1779,12 @@ __global__ __launch_bounds__(256) void k_explicit_v5(const double *__restrict__ 
 #pragma unroll
         for (int r = 0; r < JT; ++r) { su[r] = zero2; sv[r] = zero2; }
     }
-    const int ndots = i_end - i_begin;
+    // DOTS: lines start at plane i_org and have n_line rows; this launch covers whole chunks of them
     for (int i = i0; i < i1; ++i) {
         const long p = (long)i * sx + pbase;
         const bool more = i + 1 < i1;
         double wa = 0.0, wb = 0.0;
-        if (DOTS) { wa = wu[i - i_begin]; wb = wu[ndots - 1 - (i - i_begin)]; }     // block-uniform: scalar loads
+        if (DOTS) { wa = wu[i - i_org]; wb = wu[n_line - 1 - (i - i_org)]; }          // block-uniform: scalar loads
         if (more) {
             load_plane(i + 2, tq);
             load_meta(i + 1, fln, ken, hmn, hpn);
@@ -1833,7 +1833,7 @@ __global__ __launch_bounds__(256) void k_explicit_v5(const double *__restrict__ 
     }
     if (DOTS) {
         const long nlines = (long)ny * nz;
-        double *pu = part + (long)ic * 2 * nlines, *pv = pu + nlines;
+        double *pu = part + (long)((i_begin - i_org) / ichunk + ic) * 2 * nlines, *pv = pu + nlines;   // global chunk id
 #pragma unroll
         for (int r = 0; r < JT; ++r)
             if (kin && j0 + r < jend) {
@@ -2545,11 +2545,11 @@ int adi_explicit_rhs_planes(const double *d_T, const uint8_t *d_flags, int nx, i
         if (jt5 == 2)
             hipLaunchKernelGGL(k_explicit_v5<2>, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
                                L, invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end, (const double *)nullptr,
-                               (double *)nullptr);
+                               (double *)nullptr, 0, 0);
         else
             hipLaunchKernelGGL(k_explicit_v5<4>, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
                                L, invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end, (const double *)nullptr,
-                               (double *)nullptr);
+                               (double *)nullptr, 0, 0);
     } else if (fast && (ver == 3 || np != nx)) {
         const int jslab = (ny + 7) / 8;
         const int nslab = (ny + jslab - 1) / jslab;
@@ -2651,26 +2651,34 @@ int adi_axis0_classify(const uint8_t *d_flags, const uint8_t *d_dir_mask, int nx
     return ADI_OK;
 }
 
+int adi_axis0_dots_ichunk(int n_line) { return dots_ichunk(n_line); }
+
 int adi_explicit_rhs_dots(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride,
                           double dx, double dt, double kappa, double theta, double *d_R0, int i_begin, int i_end,
-                          const double *d_weights, double *d_part, void *stream)
+                          int i_org, int n_line, const double *d_weights, double *d_part, void *stream)
 {
     ADI_REQUIRE(d_T && d_flags && d_R0 && d_weights && d_part, "adi_explicit_rhs_dots: null argument");
     ADI_REQUIRE(d_T != d_R0, "adi_explicit_rhs_dots: output aliases input");
     Lay L;
     if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
-    ADI_REQUIRE(i_begin >= 0 && i_end <= nx && i_end - i_begin >= 2, "adi_explicit_rhs_dots: bad plane range [%d, %d)",
-                i_begin, i_end);
+    ADI_REQUIRE(i_begin >= 0 && i_end <= nx && i_begin < i_end, "adi_explicit_rhs_dots: bad plane range [%d, %d)", i_begin,
+                i_end);
+    ADI_REQUIRE(n_line >= 2 && i_org >= 0 && i_org + n_line <= nx && i_begin >= i_org && i_end <= i_org + n_line,
+                "adi_explicit_rhs_dots: planes [%d, %d) outside the lines [%d, %d)", i_begin, i_end, i_org, i_org + n_line);
     ADI_REQUIRE((nz % 2 == 0) && (L.sx % 2 == 0) && ((((uintptr_t)d_T | (uintptr_t)d_R0 | (uintptr_t)d_part) & 15) == 0) &&
                     (((uintptr_t)d_flags & 1) == 0),
                 "adi_explicit_rhs_dots: needs even nz / plane stride and 16-byte aligned fields");
     const int np = i_end - i_begin;
     const int jslab = (ny + 7) / 8, nslab = (ny + jslab - 1) / jslab, ktiles = (nz + 511) / 512;
-    const int ichunk = dots_ichunk(np), nchunk = (np + ichunk - 1) / ichunk;
+    // chunks of planes are counted from the start of the lines: a launch on part of the planes (interior first, the
+    // planes next to the halos once those have landed) covers whole chunks, except at the end of the lines
+    const int ichunk = dots_ichunk(n_line), nchunk = (np + ichunk - 1) / ichunk;
+    ADI_REQUIRE((i_begin - i_org) % ichunk == 0 && ((i_end - i_org) % ichunk == 0 || i_end == i_org + n_line),
+                "adi_explicit_rhs_dots: plane range [%d, %d) does not cover whole chunks of %d planes", i_begin, i_end, ichunk);
     const long ntiles = (long)nslab * nchunk * ((jslab + 1) / 2) * ktiles;
     hipLaunchKernelGGL((k_explicit_v5<2, true>), dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
                        L, 1.0 / (dx * dx), dt * kappa * (1.0 - theta), jslab, ktiles, ichunk, ntiles, i_begin, i_end,
-                       d_weights, d_part);
+                       d_weights, d_part, i_org, n_line);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }

@@ -292,11 +292,15 @@ class HipEngine:
         """share of the lines adi_axis0_classify left to the per-line condensation (reads one int: synchronises)"""
         return int(dd['list'][0].item()) / float(dd['cls'].numel())
 
-    def explicit_dots(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin, i_end, dd):
+    def dots_ichunk(self, n_line):
+        return int(self.lib.adi_axis0_dots_ichunk(n_line))
+
+    def explicit_dots(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin, i_end, dd, i_org, n_line):
+        """planes [i_begin, i_end) of lines that occupy planes [i_org, i_org + n_line): whole chunks of dots_ichunk(n_line)"""
         h = self.hip
         self.check(self.lib.adi_explicit_rhs_dots(h._p(T_ext), h._p(flags_ext), L.nx, L.ny, L.nz, L.sx, dx, dt, kappa,
-                                                  theta, h._p(out_ext), i_begin, i_end, h._p(dd['weights']),
-                                                  h._p(dd['part']), h._stream()))
+                                                  theta, h._p(out_ext), i_begin, i_end, i_org, n_line,
+                                                  h._p(dd['weights']), h._p(dd['part']), h._stream()))
 
     def dots_finish(self, variant, Li, dd, r0, flags, pack, theta, gam, dt, Tinf, line_begin, line_end, cond):
         h = self.hip
@@ -791,11 +795,21 @@ class SlabStepper:
             E.sweep(0, v, Li, Ai, fl, self.packs_int[0], prm.theta, gam, prm.dt, self.Tinf, Bi)
         elif plan['dots']:
             # one pass over the slab: R0 and, per line, the two dot products of pass A (halos must have landed)
-            if halo_ev is not None and streams:
-                main.wait_event(halo_ev)
-            # (running the explicit stage chunk by chunk of lines, so that a chunk's interface exchange travels behind
+            # (running the explicit stage chunk by chunk of LINES, so that a chunk's interface exchange travels behind
             # the next chunk's explicit stage, was measured over the RCCL self-loop: no gain, 1.99 -> 2.02 ms)
-            E.explicit_dots(self.Lext, Text, self.flags_ext, self.dx, prm.dt, kappa, prm.theta, A, 1, nl + 1, plan['dd'])
+            exd = lambda b, e: E.explicit_dots(self.Lext, Text, self.flags_ext, self.dx, prm.dt, kappa, prm.theta, A, b, e,
+                                               plan['dd'], 1, nl)
+            ich = E.dots_ichunk(nl) if hasattr(E, 'dots_ichunk') else nl
+            if nl >= 3 * ich and nl % ich == 0:
+                # the chunks of planes that touch no halo run while the halo planes are in flight
+                exd(1 + ich, nl + 1 - ich)
+                if halo_ev is not None and streams:
+                    main.wait_event(halo_ev)
+                exd(1, 1 + ich); exd(nl + 1 - ich, nl + 1)
+            else:
+                if halo_ev is not None and streams:
+                    main.wait_event(halo_ev)
+                exd(1, nl + 1)
             mark()
             ev_x = self._axis0_pipeline(plan, Ai, Bi)
             self._axis0_finish(plan, Ai, Bi, ev_x)
@@ -836,7 +850,7 @@ class SlabStepper:
                                      tuple(None if t is None else t[p0:p1] for t in pk2), prm.theta, gam, prm.dt,
                                      self.Tinf, Oi[p0:p1])
         # the fused passes and the 'window' form start with planes that need the halos: send them early
-        if prefetch_halo and self.world > 1 and nl >= 4 and (plan['mode'] == 'window' or fused or plan['dots']):
+        if prefetch_halo and self.world > 1 and nl >= 4 and (plan['mode'] == 'window' or fused):
             sw2(0, 1); sw2(nl - 1, nl)                        # the two planes the neighbours need
             if streams:
                 ev0 = torch.cuda.Event(); ev0.record(main)

@@ -172,7 +172,9 @@ int adi_explicit_condense0(int variant, const double *d_T, long valid_lo, long v
  * writes R0, so the slab's inputs are read once.  Lines that are not uniform are condensed from the stored R0.
  *   adi_axis0_dots_setup      u for (n, theta, gam) -> d_weights[n]                       (once per dt; synchronises)
  *   adi_axis0_classify        d_cls[ny*nz] (1 = uniform) and d_list (count + ids of the others)   (once per mask)
- *   adi_explicit_rhs_dots     adi_explicit_rhs_planes + partial dot products d_part (adi_axis0_dots_workspace)
+ *   adi_explicit_rhs_dots     adi_explicit_rhs_planes + partial dot products d_part (adi_axis0_dots_workspace).  The lines
+ *                             are planes [i_org, i_org + n_line) of the array; a call may cover part of them in whole
+ *                             chunks of adi_axis0_dots_ichunk(n_line) planes (interior first, halo-adjacent planes later)
  *   adi_axis0_dots_finish     -> d_cond [6][line_end - line_begin] of the lines [line_begin, line_end), the format of
  *                             adi_sweep_condense; arrays are those of the box (nx = i_end - i_begin planes)
  */
@@ -181,9 +183,10 @@ int adi_axis0_dots_workspace(int nx, int ny, int nz, size_t *part_bytes, size_t 
 int adi_axis0_dots_setup(int n, double theta, double gam, double *d_weights, void *stream);
 int adi_axis0_classify(const uint8_t *d_flags, const uint8_t *d_dir_mask, int nx, int ny, int nz, long plane_stride,
                        uint8_t *d_cls, unsigned *d_list, void *stream);
+int adi_axis0_dots_ichunk(int n_line);   /* planes per chunk of partial sums for lines of n_line rows */
 int adi_explicit_rhs_dots(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride,
                           double dx, double dt, double kappa, double theta, double *d_R0, int i_begin, int i_end,
-                          const double *d_weights, double *d_part, void *stream);
+                          int i_org, int n_line, const double *d_weights, double *d_part, void *stream);
 int adi_axis0_dots_finish(int variant, const double *d_part, const double *d_weights, const uint8_t *d_cls,
                           const unsigned *d_list, const double *d_R0, const uint8_t *d_flags, const double *d_coeff,
                           const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux,

@@ -135,7 +135,7 @@ class CpuEngine:
     def dots_setup(self, Li, flags_int, dmask_int, theta, gam):
         return {}
 
-    def explicit_dots(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin, i_end, dd):
+    def explicit_dots(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin, i_end, dd, i_org, n_line):
         self.explicit(L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin, i_end)
 
     def dots_finish(self, variant, Li, dd, r0, flags, pack, theta, gam, dt, Tinf, line_begin, line_end, cond):
