@@ -2812,6 +2812,13 @@ int adi_explicit_fused_supported(int nx, int ny, int nz, long plane_stride, int 
     // 2 GiB only the GENERAL fused kernel could run, and the separate explicit stage + sweep are faster than that
     const long sx = plane_stride ? plane_stride : (long)ny * nz;
     if (((long)nx + 2) * sx * 8 + ((long)nz + 64) * 16 >= 0x7ffff000L) return 0;
+    // lines the FAST fused kernel cannot tile (16-line tiles of at most 32 segments of 8 / 16 rows, nz a multiple of 16)
+    // would all run through the GENERAL fused kernel, which is slower than the separate explicit stage + sweep
+    // (640 x 512 x 512: 5.1 ms fused-GENERAL against 2.4 ms): decline, except for short lines where nothing is tiled anyway
+    if (nx >= 64) {
+        const bool fast_ok = (nz % 16 == 0) && (nx <= 256 ? (nx % 8 == 0) : (nx % 16 == 0 && nx / 16 <= 32));
+        if (!fast_ok) return 0;
+    }
     return pass == 0 ? (nx <= kMaxFastLine) : (condense_is_tiled(0, nx) ? 1 : 0);
 }
 

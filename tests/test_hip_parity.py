@@ -251,7 +251,9 @@ def test_fused_explicit_sweep0_is_bit_identical(hip, shape, fill, bc):
     dx = 1e-3
     alpha = 54.0 / (7800.0 * 490.0)
     grid = hip.Grid3D(*shape, dx, mask)
-    assert hip.fused_supported(grid)
+    # (fused_supported() declines boxes the FAST fused kernel cannot tile -- e.g. nz % 16 != 0 -- because the step is
+    # faster unfused there; the entry point itself still serves them, through the GENERAL fused kernel)
+    assert hip.fused_supported(grid) == (shape[0] < 64 or (shape[2] % 16 == 0 and (shape[0] % 8 == 0 if shape[0] <= 256 else shape[0] % 16 == 0)))
     mat = hip.Material(7800.0, 490.0, 54.0)
     prm = hip.Params(150.0 * dx * dx / alpha, 0.5)
     kw = dict(robin_h=350.0)
