@@ -2148,8 +2148,18 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
     const bool aligned = (((uintptr_t)in | (uintptr_t)coeff | (uintptr_t)out | (uintptr_t)dval | (uintptr_t)qf) & 15) == 0 &&
                          (((uintptr_t)flags | (uintptr_t)dmask) & 7) == 0 && (L.sx % 8 == 0);
     const bool vec = aligned && (n % M == 0);
-    // FAST kernel: 16 rows per lane from n = 257 (two lines per wave: one PCR of 5 steps serves 1024 cells)
-    const int Mf = (n > 256 && n % 16 == 0 && n / 16 <= 64) ? 16 : M;
+    // FAST kernel: as many rows per lane as divide the line (16, else 8), so that one in-wave PCR serves several lines --
+    // n = 512: two lines per wave, n = 256: four (with the GENERAL kernel's 4 rows per lane the PCR ran over 64 lanes per
+    // line: 155 Gcell/s at 256^3 against 311 at nz = 512)
+    static int fm = -1;
+    if (fm < 0) { const char *e = getenv("ADI_CONTIG_FAST_M"); fm = e ? atoi(e) : 0; }
+    int Mf = M;
+    if (fm == 0) {
+        if (n >= 128 && n % 16 == 0 && n / 16 <= 64) Mf = 16;
+        else if (n >= 64 && n % 8 == 0 && n / 8 <= 64 && M < 8) Mf = 8;
+    } else if (fm == 1) {
+        Mf = (n > 256 && n % 16 == 0 && n / 16 <= 64) ? 16 : M;     // the earlier rule, for comparison
+    }
     const int lwf = 64 / next_pow2((n + Mf - 1) / Mf);
     const long nunits_f = (nlines + lwf - 1) / lwf;
     const bool fast = use_fast(s, work, work_bytes, nunits_f) && (n % Mf == 0) && (lwf % lw == 0);
@@ -2160,6 +2170,8 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
         const bool vecf = aligned && (n % Mf == 0);
         if (Mf == 16 && M != 16)
             launch_contig_fast<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, vecf, nunits_f, queue, st);
+        else if (Mf == 8 && M != 8)
+            launch_contig_fast<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, vecf, nunits_f, queue, st);
         else
             launch_contig_fast<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, vecf, nunits_f, queue, st);
         ggrid = grid < 2048u ? grid : 2048u;
