@@ -2211,7 +2211,14 @@ struct StridedPlan {
 // 5.1 TB/s), so the FAST kernel (uniform interior, registers only for `in`) takes n/16 rows per thread and 32 lines
 // in a 512-thread workgroup; the GENERAL kernel keeps 8 rows per thread (register budget) on tiles of 16 or 32 of
 // the same lines, `ratio` of them per FAST tile.
-static StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok)
+static int strided_m32()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ADI_STRIDED_M32"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
+static StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok, bool fused = false)
 {
     StridedPlan P;
     const int n = g.n;
@@ -2226,7 +2233,11 @@ static StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok)
         // 32-line tiles with n/16 rows per thread: only where the kernel keeps few arrays alive (pass A); the solve
         // kernel needs > 200 VGPRs at 32 rows per thread and runs faster on 16-line tiles with 16 rows
         if (wide_ok && n % 16 == 0 && (n / 16 == 8 || n / 16 == 16 || n / 16 == 32)) { mf = n / 16; lf = 32; }   // Lpf = 16
-        else {
+        else if (n > 512 && n % 32 == 0 && n / 32 <= 32 && !fused && strided_m32() && g.stride <= 131072) {
+            // long lines, rows less than 1 MiB apart: 32 rows per thread keep 16-line tiles in 512 threads (1024 x 128 x 256:
+            // 112 -> 182 Gcell/s); with 2 MiB planes the 8-line tiles of 16 rows are the faster ones (233 vs 212)
+            mf = 32; lf = 16;
+        } else {
             const int m2 = (n > 256) ? 16 : 8;
             if (n % m2 == 0 && n / m2 <= 64) { mf = m2; lf = (16 * next_pow2(n / m2) > 512) ? 8 : 16; }
         }
@@ -2366,7 +2377,7 @@ static int sweep_dispatch(int axis, const double *in, const uint8_t *flags, cons
     } else {
         static int wide = -1;
         if (wide < 0) wide = getenv("ADI_STRIDED_WIDE") ? atoi(getenv("ADI_STRIDED_WIDE")) : 0;
-        StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr, wide != 0 && fzp == nullptr);
+        StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr, wide != 0 && fzp == nullptr, fzp != nullptr);
         unsigned *queue = nullptr;
         if (P.Mf && use_fast(s, work, work_bytes, P.ntiles_f)) queue = (unsigned *)work;
         else if (P.Mf) P = strided_plan(g, false, false);
@@ -2413,7 +2424,7 @@ static int condense_dispatch(int axis, const double *in, const uint8_t *flags, c
     bool tiled = false;
     StridedPlan P;
     if (axis != 2 && n <= kMaxFastLine) {
-        P = strided_plan(g, s.sparse != 0 && work != nullptr, fzp == nullptr);
+        P = strided_plan(g, s.sparse != 0 && work != nullptr, fzp == nullptr, fzp != nullptr);
         tiled = (n % P.Mg == 0) && (n / P.Mg <= 64);     // the tiled kernels need whole segments
     }
     if (fzp != nullptr && (axis != 0 || !tiled))
