@@ -351,3 +351,58 @@ def test_curved_solids_surface_segments(hip, shape, bc):
     want = run_cart_case(orc, c)['T_final']
     assert rel_linf(got, want) <= TOL, rel_linf(got, want)
     assert np.array_equal(got[~mask], c['T0'][~mask])
+
+
+def _blobs(shape, rng, nblob):
+    """union of random ellipsoids and boxes, minus a few: smooth surfaces, flat faces, concavities and inner voids"""
+    g = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing='ij')
+    m = np.zeros(shape, bool)
+    for b in range(nblob):
+        c = [rng.uniform(0.15, 0.85) * n for n in shape]
+        r = [max(1.5, rng.uniform(0.08, 0.45) * n) for n in shape]
+        if rng.random() < 0.5:
+            blob = sum(((g[a] - c[a]) / r[a]) ** 2 for a in range(3)) <= 1.0
+        else:
+            blob = np.ones(shape, bool)
+            for a in range(3):
+                blob &= np.abs(g[a] - c[a]) <= r[a]
+        if b >= 2 and rng.random() < 0.35:
+            m &= ~blob
+        else:
+            m |= blob
+    return m
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_structured_masks_fuzz(hip, seed):
+    """random unions / differences of ellipsoids and boxes on grids whose long axis takes the 8-, 16- and 32-row tilings
+    (padding, off-mask, TAIL and HEAD segments, queued GENERAL units in one sweep), random BC mix, vs the oracle"""
+    from oracle import adi_oracle as orc
+    rng = np.random.default_rng(1000 + seed)
+    longs = [64, 96, 128, 160, 256, 320, 384, 512, 640]
+    n = int(rng.choice(longs))
+    others = [int(rng.choice([8, 16, 24, 32, 48])) for _ in range(2)]
+    ax = seed % 3
+    shape = others[:]
+    shape.insert(ax, n)
+    shape = tuple(shape)
+    if seed % 4 == 3:                                    # two long axes
+        shape = tuple(int(rng.choice([96, 128, 160])) if a != ax else min(n, 256) for a in range(3))
+    mask = _blobs(shape, rng, int(rng.integers(2, 6)))
+    if not mask.any():
+        mask[tuple(s // 2 for s in shape)] = True
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    kind = seed % 3
+    dm = (rng.random(shape) > 0.985) & mask if kind == 0 else None
+    neumann = {'x+': 1e5, 'z-': rng.uniform(0, 2e5, shape), 'y-': 5e4} if kind in (0, 1) else None
+    robin = [250.0, {'x-': 100.0, 'y+': 60.0, 'z+': rng.uniform(0, 700, shape)}, rng.uniform(0, 500, shape)][seed % 3]
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,
+             T0=rng.uniform(20.0, 1200.0, shape), dir_mask=dm,
+             dir_value=(rng.uniform(50, 90, shape) if dm is not None else None), neumann=neumann, robin_h=robin, Tinf=25.0,
+             theta=float(rng.choice([0.5, 1.0])), dt=float(rng.choice([2.0, 60.0, 700.0])) * dx * dx / alpha, nsteps=2,
+             births=None)
+    got = run_cart_case(hip, c)['T_final']
+    want = run_cart_case(orc, c)['T_final']
+    assert rel_linf(got, want) <= TOL, (shape, kind, rel_linf(got, want))
+    assert np.array_equal(got[~mask], c['T0'][~mask])
