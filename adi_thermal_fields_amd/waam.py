@@ -187,9 +187,17 @@ def run_single_track(backend, plate_mask, track_box, dx, mat_args, h, Tinf, T_tr
     if device_resident and _is_device_backend(backend):
         T = backend.to_device(T)
     robin = {f: h for f in ('x-', 'x+', 'y-', 'y+', 'z-', 'z+')}
+    dev_loop = device_resident and hasattr(grid, 'set_mask_device') and hasattr(T, 'fill_where')
+    if dev_loop:                                    # the mask lives in HBM: a new column is two slice assignments
+        import torch
+        d_mask = grid.layout.to_layout(mask, torch.uint8)
     for yi in range(ncol):
-        mask[x0:x1, yi:yi + 1, z0:z1] = True
-        grid.mask = mask
+        if dev_loop:
+            d_mask[x0:x1, yi:yi + 1, z0:z1] = 1
+            grid.set_mask_device(d_mask)
+        else:
+            mask[x0:x1, yi:yi + 1, z0:z1] = True
+            grid.mask = mask
         packs = backend.precompute_coeff_packs_unified(grid, mat, robin_h=robin, robin_Tinf=Tinf)
         T[x0:x1, yi:yi + 1, z0:z1] = T_track
         n_sub = max(1, int(math.ceil(t_step / dt)))
