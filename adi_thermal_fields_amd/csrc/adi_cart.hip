@@ -95,7 +95,9 @@ __device__ __forceinline__ bool axis_exposed(unsigned f, int lbit)
 //   TAIL  block rows [M-1-L, M-1) in the mask down to the in-mask separator, the rows above them outside: the line
 //         STARTS inside the segment        HEAD  block rows [0, L) in the mask below an in-mask previous row, the rest
 //         of the segment (separator included) outside: the line ENDS inside the segment.   (adi_core.hpp, mixed_*)
-enum { SEG_NONE = 0, SEG_UNI = 1, SEG_OFF = 2, SEG_PAD = 3, SEG_TAIL = 4, SEG_HEAD = 5 };
+//   ISLAND an in-mask run of at most 8 rows that starts and ends inside the block, separator outside (thin walls):
+//         decoupled from the rest of the line, solved on the spot (island_solve); L | (first row << 8) is returned
+enum { SEG_NONE = 0, SEG_UNI = 1, SEG_OFF = 2, SEG_PAD = 3, SEG_TAIL = 4, SEG_HEAD = 5, SEG_ISLAND = 6 };
 
 template <int M>
 __device__ __forceinline__ int classify_mixed(unsigned inm, unsigned f0, int lbit, int &L)
@@ -110,6 +112,9 @@ __device__ __forceinline__ int classify_mixed(unsigned inm, unsigned f0, int lbi
     } else {                                       // separator outside: rows [0, e) in, previous row in the mask
         const int e = __popc(inm);
         if (inm == ((1u << e) - 1u) && ((f0 >> lbit) & 1u)) { L = e; return SEG_HEAD; }
+        // ... or one short run [m, m + e) with nothing in the mask before it (thin wall)
+        const int m = __ffs(inm) - 1;
+        if (e <= 8 && (inm >> m) == ((1u << e) - 1u) && (m >= 1 || !((f0 >> lbit) & 1u))) { L = e | (m << 8); return SEG_ISLAND; }
     }
     return SEG_NONE;
 }
@@ -198,6 +203,33 @@ __device__ __forceinline__ void mixed_lane_condense(int kind, int L, const UniC<
                                                     Cond &k)
 {
     constexpr int MI = M - 1;
+    if (kind == SEG_ISLAND) {
+        const int m = L >> 8, len = L & 255, e = m + len;
+        double bS = b0, bE = U.bu;                          // a run that starts at row 0: fast_segment_ends assembled it
+        if (m >= 1) {
+            const double co = coeff0[(long)m * rstride], q = HAS_Q ? qf0[(long)m * rstride] : 0.0;
+            double din = 0.0, am, cm, dm;
+#pragma unroll
+            for (int r = 1; r < MI; ++r) din = (r == m) ? d[r] : din;
+            assemble_row<false, HAS_Q>(true, false, len > 1, false, din, co, 0.0, q, s, am, bS, cm, dm);
+#pragma unroll
+            for (int r = 1; r < MI; ++r) d[r] = (r == m) ? dm : d[r];
+        }
+        if (len > 1) {
+            const double co = coeff0[(long)(e - 1) * rstride], q = HAS_Q ? qf0[(long)(e - 1) * rstride] : 0.0;
+            double din = 0.0, am, cm, dm;
+#pragma unroll
+            for (int r = 1; r < MI; ++r) din = (r == e - 1) ? d[r] : din;
+            assemble_row<false, HAS_Q>(true, true, false, false, din, co, 0.0, q, s, am, bE, cm, dm);
+#pragma unroll
+            for (int r = 1; r < MI; ++r) d[r] = (r == e - 1) ? dm : d[r];
+        }
+        island_solve<M>(U, d, m, len, bS, bE);
+        k.gF = d[0]; k.gL = d[MI - 1];
+        k.aF = k.cF = k.aL = k.cL = 0.0;
+        bmod = 1.0;
+        return;
+    }
     const bool tail = kind == SEG_TAIL;
     const int rmod = tail ? MI - L : L - 1;                 // the line-start / line-end row of the run
     bmod = b0;                                              // head run of one row: row 0 is that row, already assembled
@@ -231,9 +263,9 @@ __device__ __forceinline__ void mixed_lane_back_solve(int kind, int L, const Uni
     if (kind == SEG_TAIL) {
         if (L >= 1) mixed_back_solve<M, true>(U, d, L, bmod, U.s, xS);
         d[M - 1] = xS;
-    } else {
+    } else if (kind == SEG_HEAD) {
         mixed_back_solve<M, false>(U, d, L, bmod, a0, xL);
-    }
+    }                                                       // (an ISLAND was solved when it was condensed)
 }
 
 // ------------------------------------------------------------------------------------------------

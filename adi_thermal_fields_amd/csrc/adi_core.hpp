@@ -254,6 +254,43 @@ __device__ __forceinline__ void mixed_back_solve(const UniC<M> &U, double (&d)[M
     }
 }
 
+// ISLAND: an in-mask run [m, m+L) of at most 8 rows that starts and ends inside the block (thin walls): nothing couples it
+// to the rest of the line, so it is solved on the spot -- Thomas with L reciprocals, the inverse pivots kept in 8
+// registers addressed by (row & 7), which is unique inside a run of at most 8 rows.  bS / bE: diagonals of its first /
+// last row (line start / line end; bS alone when L == 1).
+template <int M>
+__device__ __forceinline__ void island_solve(const UniC<M> &U, double (&d)[M], int m, int L, double bS, double bE)
+{
+    constexpr int MI = M - 1;
+    const int e = m + L;
+    double invp[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) invp[q] = 0.0;
+#pragma unroll
+    for (int r = 0; r < MI; ++r) {
+        if (r >= m && r < e) {
+            double P = (r == m) ? bS : ((r == e - 1) ? bE : U.bu);
+            if (r > 0) {
+                if (r > m) {
+                    const double w = U.s * invp[(r - 1) & 7];
+                    d[r] = __builtin_fma(-w, d[r > 0 ? r - 1 : 0], d[r]);
+                    P = __builtin_fma(-w, U.s, P);
+                }
+            }
+            invp[r & 7] = frcp(P);
+        }
+    }
+    double xn = 0.0;
+#pragma unroll
+    for (int r = MI - 1; r >= 0; --r) {
+        if (r >= m && r < e) {
+            const double v = (r == e - 1) ? d[r] : __builtin_fma(-U.s, xn, d[r]);
+            xn = v * invp[r & 7];
+            d[r] = xn;
+        }
+    }
+}
+
 // host: constants for (s, bu)
 template <int M>
 inline UniC<M> make_unic(double tg)

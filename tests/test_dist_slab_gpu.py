@@ -164,15 +164,22 @@ def test_slabs_solid_512_lines_dots_all_ranks():
         assert rel_linf(got, want) <= 1e-12, (o, modes, rel_linf(got, want))
 
 
+@pytest.mark.parametrize('geom', ['ellipsoid', 'plates'])
 @pytest.mark.parametrize('form', ['separate', 'fused', 'dots', 'auto'])
-def test_slabs_512_planes_per_rank_curved_solid(form):
+def test_slabs_512_planes_per_rank_curved_solid(form, geom):
     """2 slabs of 512 planes (the bench's slab thickness: 32-row wide tiling of the unfused pass A, 16-row tiles of the
-    fused one) through an ellipsoid: surface segments (TAIL / HEAD) in every pass-A form, against the one-domain step"""
+    fused one) through an ellipsoid: surface segments (TAIL / HEAD) in every pass-A form, against the one-domain step;
+    'plates': the ellipsoid cut into plates 1 .. 8 planes thick across x (ISLAND segments in the pass-A condense)"""
     import adi_thermal_fields_amd.adi3d_hip_coeff as hip
     rng = np.random.default_rng(12)
     shape = (1024, 6, 32)
     g = np.meshgrid(*[(np.arange(n) + 0.5) / n - 0.5 for n in shape], indexing='ij')
     mask = (g[0] / 0.47) ** 2 + (g[1] / 0.49) ** 2 + (g[2] / 0.48) ** 2 <= 1.0
+    if geom == 'plates':
+        i = np.arange(shape[0])
+        keep = (i % 23) < (1 + (i // 23) % 8)
+        keep[500:530] = True                               # one thick plate across the slab interface
+        mask &= keep[:, None, None]
     dx = 1e-3
     alpha = 54.0 / (7800.0 * 490.0)
     c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,

@@ -353,6 +353,47 @@ def test_curved_solids_surface_segments(hip, shape, bc):
     assert np.array_equal(got[~mask], c['T0'][~mask])
 
 
+def _thin_walls(shape, axis, rng):
+    """tubes along `axis` with walls of 1 .. 9 voxels, a thin plate and a few isolated single voxels: every line across
+    a wall is a short run that starts and ends inside one register segment (ISLAND segments of the FAST kernels; walls
+    of 9 voxels and runs that straddle a segment boundary go the TAIL / HEAD / queue way)"""
+    g = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing='ij')
+    oth = [a for a in range(3) if a != axis]
+    m = np.zeros(shape, bool)
+    for wall, frac in ((1, 0.12), (2, 0.2), (4, 0.29), (6, 0.38), (9, 0.47)):
+        r = np.sqrt(((g[oth[0]] - shape[oth[0]] / 2.0) / shape[oth[0]]) ** 2 + ((g[oth[1]] - shape[oth[1]] / 2.0) / shape[oth[1]]) ** 2)
+        w = wall / float(min(shape[oth[0]], shape[oth[1]]))
+        m |= (r >= frac - w) & (r <= frac)
+    sl = [slice(None)] * 3
+    sl[axis] = slice(shape[axis] // 3, shape[axis] // 3 + 3)          # a 3-voxel plate across the tube axis
+    m[tuple(sl)] = True
+    sl[axis] = slice(0, 2)                                              # and one touching the box face
+    m[tuple(sl)] = True
+    m |= rng.random(shape) < 0.002                                      # isolated voxels
+    return m
+
+
+@pytest.mark.parametrize('shape,axis', [((256, 64, 48), 2), ((256, 48, 64), 1), ((64, 256, 48), 0), ((48, 64, 256), 0),
+                                        ((96, 96, 96), 2), ((512, 32, 32), 1)])
+@pytest.mark.parametrize('bc', ['lean', 'neumann'])
+def test_thin_walls_island_segments(hip, shape, axis, bc):
+    from oracle import adi_oracle as orc
+    rng = np.random.default_rng(sum(shape) * 3 + axis + len(bc))
+    mask = _thin_walls(shape, axis, rng)
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    kw = dict(dir_mask=None, dir_value=None, neumann=None)
+    if bc == 'neumann':
+        kw['neumann'] = {'x+': 2e5, 'y-': rng.uniform(0, 1e5, shape), 'z+': 1.5e5}
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,
+             T0=rng.uniform(20.0, 1200.0, shape), robin_h=rng.uniform(20.0, 400.0, shape), Tinf=20.0, theta=0.5,
+             dt=120.0 * dx * dx / alpha, nsteps=2, births=None, **kw)
+    got = run_cart_case(hip, c)['T_final']
+    want = run_cart_case(orc, c)['T_final']
+    assert rel_linf(got, want) <= TOL, rel_linf(got, want)
+    assert np.array_equal(got[~mask], c['T0'][~mask])
+
+
 def _blobs(shape, rng, nblob):
     """union of random ellipsoids and boxes, minus a few: smooth surfaces, flat faces, concavities and inner voids"""
     g = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing='ij')
