@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[3]: cylindrical (r, phi, z) 128 x 256 x 512 BE step on one GPU -- per-step time and GB/s
 against the 48 B/cell/step algorithmic traffic, plus parity vs the NumPy oracle on a shrink."""
-import sys, time
+import os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import adi_thermal_fields_amd.adi3d_hip_cyl as cyl
 
 
