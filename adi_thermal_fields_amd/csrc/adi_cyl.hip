@@ -264,7 +264,13 @@ __global__ __launch_bounds__(256) void k_copy(const double *__restrict__ in, dou
     if (p < n) out[p] = in[p];
 }
 
-static int strided_rows(int n) { return n <= 16 ? 2 : (n <= 32 ? 4 : (n <= 512 ? 8 : 16)); }
+static int strided_rows(int n)
+{
+    static const int force = [] { const char *e = getenv("ADI_CYL_M"); return e ? atoi(e) : 0; }();
+    if (force == 4 || force == 8 || force == 16)
+        if ((n + force - 1) / force <= 64) return force;
+    return n <= 16 ? 2 : (n <= 32 ? 4 : (n <= 512 ? 8 : 16));
+}
 static int contig_rows(int n) { return n <= 128 ? 2 : (n <= 256 ? 4 : (n <= 512 ? 8 : 16)); }
 
 template <int M, int MODE>
