@@ -95,7 +95,7 @@ __device__ __forceinline__ bool axis_exposed(unsigned f, int lbit)
 //   TAIL  block rows [M-1-L, M-1) in the mask down to the in-mask separator, the rows above them outside: the line
 //         STARTS inside the segment        HEAD  block rows [0, L) in the mask below an in-mask previous row, the rest
 //         of the segment (separator included) outside: the line ENDS inside the segment.   (adi_core.hpp, mixed_*)
-//   ISLAND an in-mask run of at most 8 rows that starts and ends inside the block, separator outside (thin walls):
+//   ISLAND an in-mask run of at most 16 rows that starts and ends inside the block, separator outside (thin walls):
 //         decoupled from the rest of the line, solved on the spot (island_solve); L | (first row << 8) is returned
 enum { SEG_NONE = 0, SEG_UNI = 1, SEG_OFF = 2, SEG_PAD = 3, SEG_TAIL = 4, SEG_HEAD = 5, SEG_ISLAND = 6 };
 
@@ -114,7 +114,7 @@ __device__ __forceinline__ int classify_mixed(unsigned inm, unsigned f0, int lbi
         if (inm == ((1u << e) - 1u) && ((f0 >> lbit) & 1u)) { L = e; return SEG_HEAD; }
         // ... or one short run [m, m + e) with nothing in the mask before it (thin wall)
         const int m = __ffs(inm) - 1;
-        if (e <= 8 && (inm >> m) == ((1u << e) - 1u) && (m >= 1 || !((f0 >> lbit) & 1u))) { L = e | (m << 8); return SEG_ISLAND; }
+        if (e <= 16 && (inm >> m) == ((1u << e) - 1u) && (m >= 1 || !((f0 >> lbit) & 1u))) { L = e | (m << 8); return SEG_ISLAND; }
     }
     return SEG_NONE;
 }

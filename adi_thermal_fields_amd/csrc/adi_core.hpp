@@ -254,10 +254,11 @@ __device__ __forceinline__ void mixed_back_solve(const UniC<M> &U, double (&d)[M
     }
 }
 
-// ISLAND: an in-mask run [m, m+L) of at most 8 rows that starts and ends inside the block (thin walls): nothing couples it
-// to the rest of the line, so it is solved on the spot -- Thomas with L reciprocals, the inverse pivots kept in 8
-// registers addressed by (row & 7), which is unique inside a run of at most 8 rows.  bS / bE: diagonals of its first /
-// last row (line start / line end; bS alone when L == 1).
+// ISLAND: an in-mask run [m, m+L) of at most 16 rows that starts and ends inside the block (thin walls): nothing couples
+// it to the rest of the line, so it is solved on the spot -- Thomas with one reciprocal chain.  The inverse pivots of the
+// even rows are kept in 8 registers addressed by (row >> 1) & 7, unique inside a run of at most 16 rows; the back
+// substitution recomputes the pivot of an odd row from its even predecessor with the same operations (bit-identical).
+// bS / bE: diagonals of the first / last row of the run (line start / line end; bS alone when L == 1).
 template <int M>
 __device__ __forceinline__ void island_solve(const UniC<M> &U, double (&d)[M], int m, int L, double bS, double bE)
 {
@@ -266,26 +267,39 @@ __device__ __forceinline__ void island_solve(const UniC<M> &U, double (&d)[M], i
     double invp[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) invp[q] = 0.0;
+    double ipPrev = 0.0;
 #pragma unroll
     for (int r = 0; r < MI; ++r) {
         if (r >= m && r < e) {
             double P = (r == m) ? bS : ((r == e - 1) ? bE : U.bu);
             if (r > 0) {
                 if (r > m) {
-                    const double w = U.s * invp[(r - 1) & 7];
+                    const double w = U.s * ipPrev;
                     d[r] = __builtin_fma(-w, d[r > 0 ? r - 1 : 0], d[r]);
                     P = __builtin_fma(-w, U.s, P);
                 }
             }
-            invp[r & 7] = frcp(P);
+            ipPrev = frcp(P);
+            if ((r & 1) == 0) invp[(r >> 1) & 7] = ipPrev;
         }
     }
     double xn = 0.0;
 #pragma unroll
     for (int r = MI - 1; r >= 0; --r) {
         if (r >= m && r < e) {
+            double ip;
+            if ((r & 1) == 0) {
+                ip = invp[(r >> 1) & 7];
+            } else {
+                double P = (r == m) ? bS : ((r == e - 1) ? bE : U.bu);
+                if (r > m) {
+                    const double w = U.s * invp[((r > 0 ? r - 1 : 0) >> 1) & 7];
+                    P = __builtin_fma(-w, U.s, P);
+                }
+                ip = frcp(P);
+            }
             const double v = (r == e - 1) ? d[r] : __builtin_fma(-U.s, xn, d[r]);
-            xn = v * invp[r & 7];
+            xn = v * ip;
             d[r] = xn;
         }
     }

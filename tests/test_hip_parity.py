@@ -353,14 +353,14 @@ def test_curved_solids_surface_segments(hip, shape, bc):
     assert np.array_equal(got[~mask], c['T0'][~mask])
 
 
-def _thin_walls(shape, axis, rng):
+def _thin_walls(shape, axis, rng, walls=((1, 0.12), (2, 0.2), (4, 0.29), (6, 0.38), (9, 0.47))):
     """tubes along `axis` with walls of 1 .. 9 voxels, a thin plate and a few isolated single voxels: every line across
     a wall is a short run that starts and ends inside one register segment (ISLAND segments of the FAST kernels; walls
     of 9 voxels and runs that straddle a segment boundary go the TAIL / HEAD / queue way)"""
     g = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing='ij')
     oth = [a for a in range(3) if a != axis]
     m = np.zeros(shape, bool)
-    for wall, frac in ((1, 0.12), (2, 0.2), (4, 0.29), (6, 0.38), (9, 0.47)):
+    for wall, frac in walls:
         r = np.sqrt(((g[oth[0]] - shape[oth[0]] / 2.0) / shape[oth[0]]) ** 2 + ((g[oth[1]] - shape[oth[1]] / 2.0) / shape[oth[1]]) ** 2)
         w = wall / float(min(shape[oth[0]], shape[oth[1]]))
         m |= (r >= frac - w) & (r <= frac)
@@ -388,6 +388,25 @@ def test_thin_walls_island_segments(hip, shape, axis, bc):
     c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,
              T0=rng.uniform(20.0, 1200.0, shape), robin_h=rng.uniform(20.0, 400.0, shape), Tinf=20.0, theta=0.5,
              dt=120.0 * dx * dx / alpha, nsteps=2, births=None, **kw)
+    got = run_cart_case(hip, c)['T_final']
+    want = run_cart_case(orc, c)['T_final']
+    assert rel_linf(got, want) <= TOL, rel_linf(got, want)
+    assert np.array_equal(got[~mask], c['T0'][~mask])
+
+
+@pytest.mark.parametrize('shape,axis', [((256, 64, 64), 2), ((64, 256, 64), 0), ((64, 64, 256), 0), ((512, 64, 64), 1)])
+def test_mid_walls_island_segments(hip, shape, axis):
+    """walls of 10 and 13 voxels: runs of 9 .. 15 rows inside one 16-row segment (the odd-row pivots of island_solve are
+    recomputed in the back substitution), the rest cross a segment boundary (TAIL + HEAD)"""
+    from oracle import adi_oracle as orc
+    rng = np.random.default_rng(sum(shape) * 5 + axis)
+    mask = _thin_walls(shape, axis, rng, walls=((10, 0.24), (13, 0.49)))
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,
+             T0=rng.uniform(20.0, 1200.0, shape), robin_h=rng.uniform(20.0, 400.0, shape), Tinf=20.0, theta=0.5,
+             dt=120.0 * dx * dx / alpha, nsteps=2, births=None, dir_mask=None, dir_value=None,
+             neumann={'x-': 1e5, 'z+': rng.uniform(0, 1e5, shape)})
     got = run_cart_case(hip, c)['T_final']
     want = run_cart_case(orc, c)['T_final']
     assert rel_linf(got, want) <= TOL, rel_linf(got, want)
