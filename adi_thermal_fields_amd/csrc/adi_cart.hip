@@ -42,10 +42,10 @@ namespace adi {
 #endif
 constexpr bool kBufStrided = ADI_BUF_STRIDED != 0;
 #ifndef ADI_FUSE_D
-#define ADI_FUSE_D 8     // rows of j-neighbour loads in flight per thread in the fused FAST kernels (2: 0.77 ms, 4: 0.70, 8: 0.68 at 512^3)
+#define ADI_FUSE_D 8     // rows of j-neighbour loads in flight per thread in the fused FAST kernels (2: 0.77 ms, 4: 0.70, 8: 0.68, 16: 1.02 at 512^3)
 #endif
 #ifndef ADI_FUSE_OCC
-#define ADI_FUSE_OCC 4   // waves per SIMD the fused FAST kernels are compiled for (4: two 512-thread workgroups per CU)
+#define ADI_FUSE_OCC 4   // waves per SIMD the fused FAST kernels are compiled for (4: two 512-thread workgroups per CU; 3 measures the same, 2 with deeper prefetch is slower)
 #endif
 
 // output fields are written once and not read again by the writing kernel: streaming (nt) stores keep them from
