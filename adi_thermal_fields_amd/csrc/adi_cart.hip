@@ -2320,8 +2320,8 @@ static void launch_strided_fast(const StridedPlan &P, const double *in, const ui
                                 const LineGeom &g, const double *xlo, const double *xhi, SweepScal s, unsigned *queue,
                                 hipStream_t st, const Fuse &fz)
 {
-    if (FUSE && s.box)     // all-solid box (caller's hint): the build without TAIL / HEAD lanes, no spills
-        hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE, !FUSE>), dim3((unsigned)P.ntiles_f),
+    if (s.box && MF <= 16) // all-solid box (caller's hint): the build without surface-segment lanes (fused: no spills)
+        hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE, (MF > 16)>), dim3((unsigned)P.ntiles_f),
                            dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
                            P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
     else
