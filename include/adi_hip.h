@@ -115,7 +115,7 @@ int adi_explicit_rhs_planes(const double *d_T, const uint8_t *d_flags, int nx, i
  * sparse != 0 asserts the invariant of packs built by adi_build_coeffs -- coeff/qflux of this axis are zero
  * except on cells that lack an in-mask neighbour along the axis -- so the kernel loads them only there
  * (and dir_val only where dir_mask is set).  Pass 0 for hand-built packs.  Bit 1 (value 2) is an optional hint: every
- * cell of the box is in the mask (an all-solid box), which lets the fused axis-0 kernel run its leaner build.
+ * cell of the box is in the mask (an all-solid box), which lets the strided FAST kernels (fused and unfused) run their leaner build; results do not depend on it.
  * d_work/work_bytes (adi_sweep_workspace_bytes): c'/d' scratch for lines longer than the in-register limit,
  * otherwise the unit queue that lets a sparse sweep run as a FAST kernel (solid interior) followed by the
  * GENERAL kernel on the queued surface units; with NULL/0 the GENERAL kernel processes everything.
