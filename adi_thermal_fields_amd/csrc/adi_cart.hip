@@ -97,7 +97,9 @@ __device__ __forceinline__ bool axis_exposed(unsigned f, int lbit)
 //         of the segment (separator included) outside: the line ENDS inside the segment.   (adi_core.hpp, mixed_*)
 //   ISLAND an in-mask run of at most 16 rows that starts and ends inside the block, separator outside (thin walls):
 //         decoupled from the rest of the line, solved on the spot (island_solve); L | (first row << 8) is returned
-enum { SEG_NONE = 0, SEG_UNI = 1, SEG_OFF = 2, SEG_PAD = 3, SEG_TAIL = 4, SEG_HEAD = 5, SEG_ISLAND = 6 };
+//   GAP   a HEAD run [0, e) and a TAIL run [M-1-L, M-1] with rows outside the mask between them (a slot or channel cut
+//         by the line): the two runs are independent, both paths in one lane; e | (L << 8) is returned
+enum { SEG_NONE = 0, SEG_UNI = 1, SEG_OFF = 2, SEG_PAD = 3, SEG_TAIL = 4, SEG_HEAD = 5, SEG_ISLAND = 6, SEG_GAP = 7 };
 
 template <int M>
 __device__ __forceinline__ int classify_mixed(unsigned inm, unsigned f0, int lbit, int &L)
@@ -109,6 +111,12 @@ __device__ __forceinline__ int classify_mixed(unsigned inm, unsigned f0, int lbi
     if ((inm >> MI) & 1u) {                        // separator in the mask: rows [m, M) in, [0, m) out, 1 <= m <= MI
         const int m = __ffs(inm) - 1;
         if (m >= 1 && inm == (ALL & ~((1u << m) - 1u))) { L = MI - m; return SEG_TAIL; }
+        if (m == 0 && ((f0 >> lbit) & 1u)) {       // ... or [0, e) in, a gap, [M-1-L2, M) in; previous row in the mask
+            const int e = __ffs(~inm) - 1;         // (inm != ALL here: a full segment is UNI or queued before this)
+            const unsigned hi = inm >> e;
+            const int z = __ffs(hi) - 1, n2 = __popc(hi);
+            if (e >= 1 && e < MI && z >= 1 && (hi >> z) == ((1u << n2) - 1u)) { L = e | ((n2 - 1) << 8); return SEG_GAP; }
+        }
     } else {                                       // separator outside: rows [0, e) in, previous row in the mask
         const int e = __popc(inm);
         if (inm == ((1u << e) - 1u) && ((f0 >> lbit) & 1u)) { L = e; return SEG_HEAD; }
@@ -199,10 +207,42 @@ __device__ __forceinline__ void assemble_row(bool m, bool mL, bool mR, bool dir,
 template <int M, bool HAS_Q>
 __device__ __forceinline__ void mixed_lane_condense(int kind, int L, const UniC<M> &U, const SweepScal &s,
                                                     const double *__restrict__ coeff0, const double *__restrict__ qf0,
-                                                    long rstride, double a0, double b0, double (&d)[M], double &bmod,
+                                                    long rstride, double a0, double b0, double (&d)[M], double2 &bm,
                                                     Cond &k)
 {
     constexpr int MI = M - 1;
+    double &bmod = bm.x;
+    if (kind == SEG_GAP) {                                  // HEAD run [0, e1) and TAIL run [MI - L2, MI]: independent
+        const int e1 = L & 255, L2 = L >> 8;
+        double G = 0.0, A = 0.0;
+        bm.x = b0;
+        if (e1 > 1) {
+            const int rm = e1 - 1;
+            const double co = coeff0[(long)rm * rstride], q = HAS_Q ? qf0[(long)rm * rstride] : 0.0;
+            double din = 0.0, am, cm, dm;
+#pragma unroll
+            for (int r = 1; r < MI; ++r) din = (r == rm) ? d[r] : din;
+            assemble_row<false, HAS_Q>(true, true, false, false, din, co, 0.0, q, s, am, bm.x, cm, dm);
+#pragma unroll
+            for (int r = 1; r < MI; ++r) d[r] = (r == rm) ? dm : d[r];
+        }
+        mixed_condense<M, false>(U, d, e1, bm.x, a0, G, A);
+        k.gF = G; k.aF = A; k.cF = 0.0;
+        bm.y = 1.0;
+        if (L2 >= 1) {
+            const int rm = MI - L2;
+            const double co = coeff0[(long)rm * rstride], q = HAS_Q ? qf0[(long)rm * rstride] : 0.0;
+            double din = 0.0, am, cm, dm;
+#pragma unroll
+            for (int r = 1; r < MI; ++r) din = (r == rm) ? d[r] : din;
+            assemble_row<false, HAS_Q>(true, false, true, false, din, co, 0.0, q, s, am, bm.y, cm, dm);
+#pragma unroll
+            for (int r = 1; r < MI; ++r) d[r] = (r == rm) ? dm : d[r];
+            mixed_condense<M, true>(U, d, L2, bm.y, U.s, G, A);
+        }
+        k.gL = (L2 >= 1) ? G : d[MI - 1]; k.aL = 0.0; k.cL = (L2 >= 1) ? A : 0.0;
+        return;
+    }
     if (kind == SEG_ISLAND) {
         const int m = L >> 8, len = L & 255, e = m + len;
         double bS = b0, bE = U.bu;                          // a run that starts at row 0: fast_segment_ends assembled it
@@ -257,10 +297,16 @@ __device__ __forceinline__ void mixed_lane_condense(int kind, int L, const UniC<
 }
 
 template <int M>
-__device__ __forceinline__ void mixed_lane_back_solve(int kind, int L, const UniC<M> &U, double bmod, double a0,
+__device__ __forceinline__ void mixed_lane_back_solve(int kind, int L, const UniC<M> &U, double2 bm, double a0,
                                                       double (&d)[M], double xL, double xS)
 {
-    if (kind == SEG_TAIL) {
+    const double bmod = bm.x;
+    if (kind == SEG_GAP) {
+        const int e1 = L & 255, L2 = L >> 8;
+        mixed_back_solve<M, false>(U, d, e1, bm.x, a0, xL);
+        if (L2 >= 1) mixed_back_solve<M, true>(U, d, L2, bm.y, U.s, xS);
+        d[M - 1] = xS;
+    } else if (kind == SEG_TAIL) {
         if (L >= 1) mixed_back_solve<M, true>(U, d, L, bmod, U.s, xS);
         d[M - 1] = xS;
     } else if (kind == SEG_HEAD) {
@@ -603,7 +649,7 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
         kappa = 0.0; aS = 0.0; bS = 1.0; cS = 0.0;
         if (pad) d[M - 1] = 0.0;
     }
-    double bmod = 1.0;
+    double2 bmod = make_double2(1.0, 1.0);
     if (kind >= SEG_TAIL) mixed_lane_condense<M, HAS_Q>(kind, Lm, U, s, coeff + base, qf + base, 1L, a0, b0, d, bmod, k);
     const double gFn = __shfl_down(k.gF, 1, Lp), aFn = __shfl_down(k.aF, 1, Lp), cFn = __shfl_down(k.cF, 1, Lp);
     double ra, rb, rc, rd;
@@ -1166,7 +1212,7 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
         kappa = 0.0; aS = 0.0; bS = 1.0; cS = 0.0;
         if (pad) d[M - 1] = 0.0;
     }
-    double bmod = 1.0;
+    double2 bmod = make_double2(1.0, 1.0);
     if constexpr (MIXED) {
         if (kind >= SEG_TAIL)                      // the surface crosses the segment once (adi_core.hpp, mixed_*)
             mixed_lane_condense<M, HAS_Q>(kind, Lm, U, s, coeff + base + (long)r0 * g.stride,
@@ -1362,7 +1408,7 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_condense_strid
         ki.aF = ki.cF = ki.aL = ki.cL = 0.0;
         aS = 0.0; bS = 1.0; cS = 0.0;
     } else if (kind >= SEG_TAIL) {                 // the surface crosses the segment once
-        double bmod;
+        double2 bmod;
         mixed_lane_condense<M, HAS_Q>(kind, Lm, U, s, coeff + base + (long)r0 * g.stride,
                                       HAS_Q ? qf + base + (long)r0 * g.stride : qf, g.stride, a0, b0, d, bmod, ki);
     }

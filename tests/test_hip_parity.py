@@ -413,6 +413,40 @@ def test_mid_walls_island_segments(hip, shape, axis):
     assert np.array_equal(got[~mask], c['T0'][~mask])
 
 
+@pytest.mark.parametrize('shape', [(256, 64, 64), (64, 256, 64), (64, 64, 256), (96, 128, 96)])
+@pytest.mark.parametrize('bc', ['lean', 'neumann'])
+def test_slots_gap_segments(hip, shape, bc):
+    """a solid block with slots 1 .. 12 voxels wide cut across every axis at irregular positions: lines cross a slot
+    inside one register segment (GAP: a HEAD run and a TAIL run in one lane), at its edge (HEAD | TAIL) or twice (queued)"""
+    from oracle import adi_oracle as orc
+    rng = np.random.default_rng(sum(shape) * 7 + len(bc))
+    mask = np.ones(shape, bool)
+    for ax in range(3):
+        pos = 5
+        for w in (1, 3, 6, 9, 12, 2, 5):
+            pos += int(rng.integers(9, 30))
+            if pos + w >= shape[ax] - 3:
+                break
+            sl = [slice(None)] * 3
+            sl[ax] = slice(pos, pos + w)
+            o = (ax + 1) % 3
+            sl[o] = slice(shape[o] // 4, shape[o])           # the slot does not cut the block in two
+            mask[tuple(sl)] = False
+            pos += w
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    kw = dict(dir_mask=None, dir_value=None, neumann=None)
+    if bc == 'neumann':
+        kw['neumann'] = {'x-': 2e5, 'y+': rng.uniform(0, 1e5, shape), 'z-': 1.5e5}
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask,
+             T0=rng.uniform(20.0, 1200.0, shape), robin_h=rng.uniform(20.0, 400.0, shape), Tinf=20.0, theta=0.5,
+             dt=120.0 * dx * dx / alpha, nsteps=2, births=None, **kw)
+    got = run_cart_case(hip, c)['T_final']
+    want = run_cart_case(orc, c)['T_final']
+    assert rel_linf(got, want) <= TOL, rel_linf(got, want)
+    assert np.array_equal(got[~mask], c['T0'][~mask])
+
+
 def _blobs(shape, rng, nblob):
     """union of random ellipsoids and boxes, minus a few: smooth surfaces, flat faces, concavities and inner voids"""
     g = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing='ij')
