@@ -74,7 +74,30 @@ def cpu_baseline(n, seed=0):
     return out
 
 
+# The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout of every process that
+# initialises it, so file descriptor 1 is pointed at stderr for the whole run and the line is written to a saved
+# duplicate of the original stdout.
+_STDOUT_FD = None
+
+
+def claim_stdout():
+    global _STDOUT_FD
+    if _STDOUT_FD is None:
+        sys.stdout.flush()
+        _STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(text):
+    sys.stdout.flush()
+    if _STDOUT_FD is None:
+        print(text, flush=True)
+    else:
+        os.write(_STDOUT_FD, (text + '\n').encode())
+
+
 def main():
+    claim_stdout()
     a = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -242,7 +265,7 @@ def main():
         st, mt = cpu_baseline(a.cpu_n)
         line['cpu_baseline'] = st
         line['cpu_baseline_all_cores'] = mt
-    print(json.dumps(line))
+    emit(json.dumps(line))
     if world > 1 or force_dist:
         dist.destroy_process_group()
 
