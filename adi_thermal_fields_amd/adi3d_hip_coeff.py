@@ -454,13 +454,22 @@ def adi_explicit_rhs(Tn, grid, mat, params):
     return _wrap(out, kind)
 
 
+def _sparse_arg(grid, pack, dense):
+    """the `sparse` argument of the sweep entry points: bit 0 = the pack arrays may be read only where the flags say a
+    cell is exposed, bit 1 = all-solid box hint.  Bit 0 needs packs built for the mask the flags describe: after
+    `grid.mask = new` WITHOUT a pack rebuild the reference pairs the stale packs with the live mask
+    (adi3d_numba_coeff.py:150-162 reads coeff at every in-mask cell), so stale packs are read densely here too."""
+    fresh = getattr(pack, 'mask_version', None) == grid.mask_version
+    return int(pack.sparse_ok and fresh and not dense) | (2 if getattr(grid, 'all_solid', False) else 0)
+
+
 def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None, xlo=None, xhi=None, dense=False):
     _, gam = _gam(grid, mat, params)
     _, work, wb = grid.scratch(2)
     v = pack.variant if variant is None else variant
     check(lib.adi_sweep(axis, v, _p(t_in), _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
                         _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
-                        int(pack.sparse_ok and not dense) | (2 if getattr(grid, 'all_solid', False) else 0), params.theta,
+                        _sparse_arg(grid, pack, dense), params.theta,
                         gam, params.dt, float(Tinf), _p(t_out),
                         _p(xlo), _p(xhi),
                         _p(work), wb, _stream()))
@@ -487,8 +496,7 @@ def _explicit_sweep0_into(t, t_out, grid, mat, params, pack, Tinf, variant=None,
     vlo, vhi = valid_range(t)
     check(lib.adi_explicit_sweep0(v, _p(t), vlo, vhi, _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
                                   _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
-                                  int(pack.sparse_ok and not dense) | (2 if getattr(grid, 'all_solid', False) else 0),
-                                  grid.dx, params.dt, kappa, params.theta,
+                                  _sparse_arg(grid, pack, dense), grid.dx, params.dt, kappa, params.theta,
                                   float(Tinf), _p(t_out), None, None, _p(work), wb, _stream()))
 
 
@@ -616,6 +624,7 @@ class StagedStepper:
         g, prm = self.grid, self.params
         nsteps = int(nsteps)
         key = (float(prm.dt), float(prm.theta), self.Tinf, g.mask_version, tuple(id(p) for p in self.packs),
+               tuple(getattr(p, 'mask_version', None) for p in self.packs),
                tuple(None if p.d_coeff is None else p.d_coeff.data_ptr() for p in self.packs), self.fused)
         st = getattr(self, '_graph', None)
         if st is None or st['key'] != key:

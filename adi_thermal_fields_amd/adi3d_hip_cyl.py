@@ -114,9 +114,11 @@ def _state(Tn, grid):
 
 
 def _run(Tn, grid, mat, prm, robin_r, zbc, S, active, T_void, T_inner):
-    if prm.scheme != "be":
-        raise NotImplementedError("adi3d_hip_cyl serves scheme='be' only: the reference's 'douglas' branch "
-                                  "is numerically broken (reads uninitialised memory), so it has no valid oracle")
+    # adi3d_cyl_phi_v3.py:335: `scheme = prm.scheme if prm.scheme in ('be', 'douglas') else 'be'` -- every string but
+    # 'douglas' is backward Euler in the reference, and so it is here
+    if prm.scheme == "douglas":
+        raise NotImplementedError("adi3d_hip_cyl does not serve scheme='douglas': the reference's branch is numerically "
+                                  "broken (reads uninitialised memory, omits alpha), so it has no valid oracle")
     t, kind = _state(Tn, grid)
     pl = _plan(grid, mat, prm.dt, robin_r, zbc)
     ta, tb = grid.scratch()

@@ -1,0 +1,216 @@
+// adi_cart_api.hip -- the C-ABI entry points of the Cartesian step (include/adi_hip.h): argument checks, the choice of
+// kernel family per axis and line length, and adi_step = adi_step_numba_coeff (adi3d_numba_coeff.py:290-302).
+// The kernels live in adi_explicit.hip, adi_sweep_contig.hip, adi_sweep_strided.hip and adi_condense.hip.
+#include "adi_cart_host.hpp"
+
+using namespace adi;
+
+extern "C" {
+
+long adi_recommended_plane_stride(int ny, int nz)
+{
+    // planes whose byte size is a multiple of 16 KiB alias on the HBM channel interleave when walked with
+    // that stride (axis-0 sweeps): pad by 256 elements (2 KiB; a sweep over 64..4608 showed 256 a few percent ahead on the axis-0 sweep).
+    const long dense = (long)ny * nz;
+    return (dense * 8 % 16384 == 0) ? dense + 256 : dense;
+}
+
+int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, long plane_stride, size_t *bytes)
+{
+    ADI_REQUIRE(axis >= 0 && axis < 3 && bytes, "adi_sweep_workspace_bytes: bad argument");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    const int nn[3] = {nx, ny, nz};
+    // long lines: c', d' scratch; otherwise the unit queue of the FAST/GENERAL kernel pair (one id per tile or
+    // line group; nx*ny*nz/8 + 1 ids is an upper bound for every tiling this library uses)
+    const size_t cells = (size_t)nx * ny * nz;
+    *bytes = nn[axis] > kMaxFastLine ? (size_t)2 * nx * L.sx * sizeof(double) : (cells / 8 + 64) * sizeof(unsigned);
+    return ADI_OK;
+}
+static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
+                       const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
+                       long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
+                       const double *d_xlo, const double *d_xhi, void *d_work, size_t work_bytes, void *stream,
+                       const Fuse *fz)
+{
+    ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep: bad axis %d", axis);
+    bool has_dir, has_q;
+    if (int rc = variant_flags(variant, &has_dir, &has_q)) return rc;
+    ADI_REQUIRE(d_in && d_flags && d_coeff && d_out, "adi_sweep: null argument");
+    ADI_REQUIRE(d_in != d_out, "adi_sweep: output aliases input");
+    ADI_REQUIRE(!has_dir || (d_dir_mask && d_dir_val), "adi_sweep: variant needs Dirichlet arrays");
+    ADI_REQUIRE(!has_q || d_qflux, "adi_sweep: variant needs the flux array");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    SweepScal s;
+    s.tg = theta * gam;
+    s.dt = dt;
+    s.Tinf = Tinf;
+    s.sparse = (sparse & 1) ? 1 : 0;
+    s.box = (sparse & 2) ? 1 : 0;
+    hipStream_t st = as_stream(stream);
+    SweepArgs a;
+    a.in = d_in; a.flags = d_flags; a.coeff = d_coeff;
+    a.dmask = has_dir ? d_dir_mask : nullptr; a.dval = has_dir ? d_dir_val : nullptr; a.qf = has_q ? d_qflux : nullptr;
+    long inner_stride;
+    const LineGeom g = line_geom(axis, L, &inner_stride);
+    const int n = g.n;
+    if (fz != nullptr && (axis != 0 || n > kMaxFastLine))
+        return set_err(ADI_ERR_UNSUPPORTED, "fused explicit + sweep: axis 0 with at most %d planes only", kMaxFastLine);
+    if (n > kMaxFastLine || (axis == 2 && (d_xlo || d_xhi))) {
+        // lines too long for the in-register partition kernels: thread-per-line Thomas with c', d' in HBM scratch
+        const size_t need = (size_t)2 * L.nx * L.sx * sizeof(double);
+        if (d_work == nullptr || work_bytes < need)
+            return set_err(ADI_ERR_ARG, "adi_sweep: this sweep (line length %d) needs a workspace of %zu bytes", n, need);
+        double *wc = (double *)d_work, *wd = wc + (size_t)L.nx * L.sx;
+        generic_sweep(has_dir, has_q, a, g, inner_stride, s, d_out, d_xlo, d_xhi, wc, wd, st);
+    } else if (axis == 2) {
+        contig_sweep(has_dir, has_q, a, L, s, d_out, d_work, work_bytes, st);
+    } else {
+        strided_sweep(has_dir, has_q, a, L, g, s, d_out, d_xlo, d_xhi, d_work, work_bytes, st, fz);
+    }
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
+              const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
+              long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
+              const double *d_xlo, const double *d_xhi, void *d_work, size_t work_bytes, void *stream)
+{
+    return sweep_entry(axis, variant, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
+                       sparse, theta, gam, dt, Tinf, d_out, d_xlo, d_xhi, d_work, work_bytes, stream, nullptr);
+}
+
+static Fuse make_fuse(int nx, int ny, int nz, long plane_stride, double dx, double dt, double kappa, double theta,
+                      long valid_lo, long valid_hi)
+{
+    Fuse fz;
+    fz.invdx2 = 1.0 / (dx * dx);                 // the same two expressions as adi_explicit_rhs_planes
+    fz.f = dt * kappa * (1.0 - theta);
+    fz.sy = nz;
+    fz.vlo = valid_lo;
+    fz.vhi = valid_hi;
+    fz.kt = 0; fz.ny = 0; fz.kg = 0;
+    fz.r0_out = nullptr;
+    // window of the state the FAST kernel's buffer descriptor covers: the box, one plane + one row + one tile around it
+    const long sx = plane_stride ? plane_stride : (long)ny * nz;
+    const long box_end = (long)(nx - 1) * sx + (long)ny * nz;
+    const long wlo = valid_lo > -(sx + nz + 16) ? valid_lo : -(sx + nz + 16);
+    const long whi = valid_hi < box_end + sx + nz + 32 ? valid_hi : box_end + sx + nz + 32;
+    fz.wlo = wlo;
+    fz.wbytes = ((whi - wlo) * 8 < 0x7ffff000L) ? (unsigned)((whi - wlo) * 8) : 0u;
+    return fz;
+}
+int adi_explicit_fused_supported(int nx, int ny, int nz, long plane_stride, int pass)
+{
+    if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
+    // the FAST fused kernel addresses the state through one buffer descriptor (box + a plane either side): beyond
+    // 2 GiB only the GENERAL fused kernel could run, and the separate explicit stage + sweep are faster than that
+    const long sx = plane_stride ? plane_stride : (long)ny * nz;
+    if (((long)nx + 2) * sx * 8 + ((long)nz + 64) * 16 >= 0x7ffff000L) return 0;
+    // lines the FAST fused kernel cannot tile (16-line tiles of at most 32 segments of 8 / 16 rows, nz a multiple of 16)
+    // would all run through the GENERAL fused kernel, which is slower than the separate explicit stage + sweep
+    // (640 x 512 x 512: 5.1 ms fused-GENERAL against 2.4 ms): decline, except for short lines where nothing is tiled anyway
+    if (nx >= 64) {
+        const bool fast_ok = (nz % 16 == 0) && (nx <= 256 ? (nx % 8 == 0) : (nx % 16 == 0 && nx / 16 <= 32));
+        if (!fast_ok) return 0;
+    }
+    return pass == 0 ? (nx <= kMaxFastLine) : (condense_is_tiled(0, nx) ? 1 : 0);
+}
+int adi_explicit_sweep0(int variant, const double *d_T, long valid_lo, long valid_hi, const uint8_t *d_flags,
+                        const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
+                        const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse, double dx,
+                        double dt, double kappa, double theta, double Tinf, double *d_out, const double *d_xlo,
+                        const double *d_xhi, void *d_work, size_t work_bytes, void *stream)
+{
+    ADI_REQUIRE(valid_lo <= 0 && valid_hi >= (long)(nx - 1) * (plane_stride ? plane_stride : (long)ny * nz) + (long)ny * nz,
+                "adi_explicit_sweep0: the readable range [%ld, %ld) does not cover the box", valid_lo, valid_hi);
+    const Fuse fz = make_fuse(nx, ny, nz, plane_stride, dx, dt, kappa, theta, valid_lo, valid_hi);
+    const double gam = kappa * dt / (dx * dx);   // adi3d_numba_coeff.py:292
+    return sweep_entry(0, variant, d_T, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
+                       sparse, theta, gam, dt, Tinf, d_out, d_xlo, d_xhi, d_work, work_bytes, stream, &fz);
+}
+static int condense_entry(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
+                          const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny,
+                          int nz, long plane_stride, int sparse, double theta, double gam, double dt, double Tinf,
+                          double *d_cond, void *d_work, size_t work_bytes, void *stream, const Fuse *fz)
+{
+    ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep_condense: bad axis %d", axis);
+    bool has_dir, has_q;
+    if (int rc = variant_flags(variant, &has_dir, &has_q)) return rc;
+    ADI_REQUIRE(d_in && d_flags && d_coeff && d_cond, "adi_sweep_condense: null argument");
+    ADI_REQUIRE(!has_dir || (d_dir_mask && d_dir_val), "adi_sweep_condense: variant needs Dirichlet arrays");
+    ADI_REQUIRE(!has_q || d_qflux, "adi_sweep_condense: variant needs the flux array");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    SweepScal s;
+    s.tg = theta * gam;
+    s.dt = dt;
+    s.Tinf = Tinf;
+    s.sparse = (sparse & 1) ? 1 : 0;
+    s.box = (sparse & 2) ? 1 : 0;
+    hipStream_t st = as_stream(stream);
+    SweepArgs a;
+    a.in = d_in; a.flags = d_flags; a.coeff = d_coeff;
+    a.dmask = has_dir ? d_dir_mask : nullptr; a.dval = has_dir ? d_dir_val : nullptr; a.qf = has_q ? d_qflux : nullptr;
+    const int rc = condense_sweep(has_dir, has_q, axis, a, L, s, d_cond, d_work, work_bytes, st, fz);
+    if (rc != ADI_OK) return rc;
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
+                       const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny,
+                       int nz, long plane_stride, int sparse, double theta, double gam, double dt, double Tinf,
+                       double *d_cond, void *d_work, size_t work_bytes, void *stream)
+{
+    return condense_entry(axis, variant, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
+                          sparse, theta, gam, dt, Tinf, d_cond, d_work, work_bytes, stream, nullptr);
+}
+
+int adi_explicit_condense0(int variant, const double *d_T, long valid_lo, long valid_hi, const uint8_t *d_flags,
+                           const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
+                           const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse, double dx,
+                           double dt, double kappa, double theta, double Tinf, double *d_cond, double *d_R0_out,
+                           void *d_work, size_t work_bytes, void *stream)
+{
+    ADI_REQUIRE(valid_lo <= 0 && valid_hi >= (long)(nx - 1) * (plane_stride ? plane_stride : (long)ny * nz) + (long)ny * nz,
+                "adi_explicit_condense0: the readable range [%ld, %ld) does not cover the box", valid_lo, valid_hi);
+    ADI_REQUIRE(d_R0_out != d_T, "adi_explicit_condense0: R0 output aliases the state");
+    Fuse fz = make_fuse(nx, ny, nz, plane_stride, dx, dt, kappa, theta, valid_lo, valid_hi);
+    fz.r0_out = d_R0_out;
+    const double gam = kappa * dt / (dx * dx);
+    return condense_entry(0, variant, d_T, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
+                          sparse, theta, gam, dt, Tinf, d_cond, d_work, work_bytes, stream, &fz);
+}
+int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b, const uint8_t *d_flags,
+             const double *const *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
+             const double *const *d_qflux, int variant, int sparse, int nx, int ny, int nz, long plane_stride,
+             double dx, double rho, double cp, double k, double dt, double theta, double Tinf, void *d_work,
+             size_t work_bytes, void *stream)
+{
+    ADI_REQUIRE(d_T_in && d_T_out && d_tmp_a && d_tmp_b && d_coeff, "adi_step: null argument");
+    ADI_REQUIRE(d_tmp_a != d_tmp_b && d_tmp_a != d_T_in && d_tmp_b != d_T_in && d_T_out != d_tmp_a && d_T_out != d_T_in,
+                "adi_step: buffers must be distinct (T_out may equal tmp_b only)");
+    // kappa, gam: adi3d_numba_coeff.py:292
+    const double kappa = k / (rho * cp);
+    const double gam = kappa * dt / (dx * dx);
+    const double *q0 = d_qflux ? d_qflux[0] : nullptr, *q1 = d_qflux ? d_qflux[1] : nullptr, *q2 = d_qflux ? d_qflux[2] : nullptr;
+    int rc;
+    if (adi_explicit_fused_supported(nx, ny, nz, plane_stride, 0)) {
+        // stages 1+2 in one pass: R0 is evaluated inside the loads of the axis-0 sweep
+        const long sxe = plane_stride ? plane_stride : (long)ny * nz;
+        rc = adi_explicit_sweep0(variant, d_T_in, 0, (long)(nx - 1) * sxe + (long)ny * nz, d_flags, d_coeff[0], d_dir_mask,
+                                 d_dir_val, q0, nx, ny, nz, plane_stride, sparse, dx, dt, kappa, theta, Tinf, d_tmp_b,
+                                 nullptr, nullptr, d_work, work_bytes, stream);
+    } else {
+        rc = adi_explicit_rhs(d_T_in, d_flags, nx, ny, nz, plane_stride, dx, dt, kappa, theta, d_tmp_a, stream);
+        if (rc) return rc;
+        rc = adi_sweep(0, variant, d_tmp_a, d_flags, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_b, nullptr, nullptr, d_work, work_bytes, stream);
+    }
+    if (rc) return rc;
+    rc = adi_sweep(1, variant, d_tmp_b, d_flags, d_coeff[1], d_dir_mask, d_dir_val, q1, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_a, nullptr, nullptr, d_work, work_bytes, stream);
+    if (rc) return rc;
+    return adi_sweep(2, variant, d_tmp_a, d_flags, d_coeff[2], d_dir_mask, d_dir_val, q2, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_T_out, nullptr, nullptr, d_work, work_bytes, stream);
+}
+}  // extern "C"

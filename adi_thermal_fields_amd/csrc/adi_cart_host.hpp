@@ -1,0 +1,168 @@
+// adi_cart_host.hpp -- host-side planning shared by the Cartesian translation units of libadi_hip.so: line geometry of
+// a sweep, the tiling of the strided kernels, and the launchers each translation unit exports to the C-ABI layer
+// (adi_cart_api.hip).  The tiling constants are the measured optima of round 1; the run-time
+// tuning knobs they were swept with are gone.
+#pragma once
+#include "adi_cart_dev.hpp"
+
+namespace adi {
+
+inline LineGeom line_geom(int axis, const Lay &L, long *inner_stride)
+{
+    LineGeom g;
+    g.lbit = 1 + 2 * axis;
+    if (axis == 0) { g.n = L.nx; g.stride = L.sx; g.n_inner = L.ny * L.nz; g.n_outer = 1; g.outer_stride = 0; *inner_stride = 1; }
+    else if (axis == 1) { g.n = L.ny; g.stride = L.nz; g.n_inner = L.nz; g.n_outer = L.nx; g.outer_stride = L.sx; *inner_stride = 1; }
+    else { g.n = L.nz; g.stride = 1; g.n_inner = L.ny; g.n_outer = L.nx; g.outer_stride = L.sx; *inner_stride = L.nz; }
+    return g;
+}
+
+// sparse packs + a workspace for the unit queue -> FAST kernel first, GENERAL kernel on what it queued
+inline bool use_fast(const SweepScal &s, void *work, size_t work_bytes, long nunits)
+{
+    return s.sparse && work != nullptr && work_bytes >= (size_t)(nunits + 1) * sizeof(unsigned);
+}
+
+inline int strided_rows_per_thread(int n) { return n <= 16 ? 2 : (n <= 32 ? 4 : (n <= 512 ? 8 : 16)); }
+
+// Tiling of a strided sweep.  `lines` adjacent lines x all segments per workgroup.  The FAST kernel (uniform
+// interior, ~70 VGPRs) takes Mf = 16 rows per thread for n > 256 so that 16 lines (whole 128-byte DRAM bursts per
+// row) still fit a 512-thread workgroup; the GENERAL kernel keeps Mg = 8 rows (register budget) and, when it runs
+// behind a FAST kernel, the same `lines`, so both see the same tile ids in the unit queue.
+struct StridedPlan {
+    int Mg, Lpg, lines_g, tiles_inner_g;    // GENERAL kernel: rows per thread, segments per line, lines per tile
+    long ntiles_g;
+    int Mf, Lpf, lines_f, tiles_inner_f;    // FAST kernel (Mf = 0: not available)
+    long ntiles_f;
+    int ratio;                              // lines_f / lines_g: GENERAL tiles per queued FAST tile
+    size_t lds_g, lds_f;
+};
+
+// Tiling of a strided sweep: `lines` adjacent lines x all segments per workgroup.  The pure-streaming rate of this
+// access pattern grows with the contiguous bytes per row (measured at 17 B/cell: 16 lines 4.3 TB/s, 32 lines
+// 5.1 TB/s), so the FAST kernel (uniform interior, registers only for `in`) takes n/16 rows per thread and 32 lines
+// in a 512-thread workgroup; the GENERAL kernel keeps 8 rows per thread (register budget) on tiles of 16 or 32 of
+// the same lines, `ratio` of them per FAST tile.
+
+inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok, bool fused = false)
+{
+    StridedPlan P;
+    const int n = g.n;
+    P.Mg = strided_rows_per_thread(n);
+    P.Lpg = next_pow2((n + P.Mg - 1) / P.Mg);
+    P.Mf = 0; P.Lpf = 0; P.lines_f = 0; P.tiles_inner_f = 0; P.ntiles_f = 0; P.ratio = 1; P.lds_f = 0;
+    int lines = 8;                                    // lines per tile of the GENERAL kernel (8 B * lines contiguous per row)
+    if (P.Mg > 8 && lines * P.Lpg > 512) lines = 8;
+    const int maxg = (P.Mg <= 8) ? 1024 : 512;
+    if (want_fast && n >= 64 && (long)n * g.stride < (1L << 31)) {   // 32-bit element offsets in the FAST kernels
+        int mf = 0, lf = 0;
+        // 32-line tiles with n/16 rows per thread: only where the kernel keeps few arrays alive (pass A); the solve
+        // kernel needs > 200 VGPRs at 32 rows per thread and runs faster on 16-line tiles with 16 rows
+        if (wide_ok && n % 16 == 0 && (n / 16 == 8 || n / 16 == 16 || n / 16 == 32)) { mf = n / 16; lf = 32; }   // Lpf = 16
+        else if (n > 512 && n % 32 == 0 && n / 32 <= 32 && !fused && g.stride <= 131072) {
+            // long lines, rows less than 1 MiB apart: 32 rows per thread keep 16-line tiles in 512 threads (1024 x 128 x 256:
+            // 112 -> 182 Gcell/s); with 2 MiB planes the 8-line tiles of 16 rows are the faster ones (233 vs 212)
+            mf = 32; lf = 16;
+        } else {
+            const int m2 = (n > 256) ? 16 : 8;
+            if (n % m2 == 0 && n / m2 <= 64) { mf = m2; lf = (16 * next_pow2(n / m2) > 512) ? 8 : 16; }
+        }
+        if (mf) {
+            const int lpf = next_pow2(n / mf);
+            int lg = lf;                                  // GENERAL lines: lf, or lf/2 when the workgroup gets too big
+            while (lg * P.Lpg > maxg && lg > 8) lg >>= 1;
+            if (lf * lpf <= 512 && lf * lpf >= 256 && lg * P.Lpg <= maxg && lg * P.Lpg >= 64) {
+                P.Mf = mf; P.Lpf = lpf; P.lines_f = lf; lines = lg; P.ratio = lf / lg;
+            }
+        }
+    }
+    if (P.Mf == 0) while (lines * P.Lpg < 256) lines <<= 1;
+    P.lines_g = lines;
+    P.tiles_inner_g = (g.n_inner + lines - 1) / lines;
+    P.ntiles_g = (long)P.tiles_inner_g * g.n_outer;
+    P.lds_g = (size_t)7 * lines * (P.Lpg + 1) * sizeof(double);
+    if (P.Mf) {
+        P.tiles_inner_f = (g.n_inner + P.lines_f - 1) / P.lines_f;
+        P.ntiles_f = (long)P.tiles_inner_f * g.n_outer;
+        P.lds_f = (size_t)7 * P.lines_f * (P.Lpf + 1) * sizeof(double);
+    }
+    return P;
+}
+
+// the fused FAST kernels shuffle k-neighbours inside 16-lane DPP rows: 16 lines per tile, at most 16 rows per thread
+inline bool fuse_fast_ok(const StridedPlan &P, const Lay &L, const Fuse &fz)
+{
+    return P.Mf != 0 && P.lines_f == 16 && P.Mf <= 16 && L.nz % 16 == 0 && fz.wbytes != 0;
+}
+
+inline void fuse_tile_order(Fuse &fz, const StridedPlan &P, const Lay &L)
+{
+    const int kg = 8;                // k-tiles per group walked j-fastest (swept 1..32 in round 1)
+    fz.kt = 0; fz.ny = L.ny; fz.kg = 0;
+    if (P.Mf != 0 && kg > 0 && L.nz % P.lines_f == 0) {
+        const int kt = L.nz / P.lines_f;
+        int k2 = kg;
+        while (k2 > 1 && kt % k2 != 0) k2 >>= 1;
+        fz.kt = kt; fz.kg = k2;          // tiles_inner_f == ny * kt: the remap is a permutation of the tile ids
+    }
+}
+
+inline int make_lay(int nx, int ny, int nz, long plane_stride, Lay *L)
+{
+    if (nx <= 0 || ny <= 0 || nz <= 0) return set_err(ADI_ERR_ARG, "bad grid %d x %d x %d", nx, ny, nz);
+    const long dense = (long)ny * nz;
+    if (plane_stride != 0 && plane_stride < dense)
+        return set_err(ADI_ERR_ARG, "plane_stride %ld < ny*nz = %ld", plane_stride, dense);
+    if (dense > 0x7fffffffL) return set_err(ADI_ERR_UNSUPPORTED, "plane of %ld cells is too large", dense);
+    L->nx = nx; L->ny = ny; L->nz = nz;
+    L->sx = plane_stride ? plane_stride : dense;
+    return ADI_OK;
+}
+
+inline unsigned cell_blocks(const Lay &L) { return (unsigned)(((long)L.nx * L.ny * L.nz + 255) / 256); }
+
+inline int variant_flags(int variant, bool *has_dir, bool *has_q)
+{
+    if (variant < 0 || variant > 3) return set_err(ADI_ERR_ARG, "bad sweep variant %d", variant);
+    *has_dir = (variant == ADI_SWEEP_GENERAL || variant == ADI_SWEEP_NO_Q);
+    *has_q = (variant == ADI_SWEEP_GENERAL || variant == ADI_SWEEP_NO_DIR);
+    return ADI_OK;
+}
+
+// whole-segment condition of the tiled pass-A kernels (also what adi_explicit_fused_supported reports)
+inline bool condense_is_tiled(int axis, int n)
+{
+    if (axis == 2 || n > kMaxFastLine) return false;
+    const int mg = strided_rows_per_thread(n);
+    return (n % mg == 0) && (n / mg <= 64);
+}
+
+inline int dots_ichunk(int np) { return np >= 512 ? 32 : (np / 16 < 4 ? 4 : np / 16); }
+
+// ---- launchers exported by the kernel translation units ----------------------------------------------------------
+// The arrays a variant does not read (has_dir / has_q false) may be null.
+struct SweepArgs {
+    const double *in;
+    const uint8_t *flags;
+    const double *coeff;
+    const uint8_t *dmask;
+    const double *dval;
+    const double *qf;
+};
+// adi_sweep_contig.hip: memory axis 2
+void contig_sweep(bool has_dir, bool has_q, const SweepArgs &a, const Lay &L, const SweepScal &s, double *out, void *work,
+                  size_t work_bytes, hipStream_t st);
+// adi_sweep_strided.hip: memory axes 0 / 1 (fz != nullptr: the explicit stage folded into the loads, axis 0), and the
+// thread-per-line sweep for lines beyond kMaxFastLine rows (HBM scratch wc, wd)
+void strided_sweep(bool has_dir, bool has_q, const SweepArgs &a, const Lay &L, const LineGeom &g, const SweepScal &s,
+                   double *out, const double *xlo, const double *xhi, void *work, size_t work_bytes, hipStream_t st,
+                   const Fuse *fz);
+void generic_sweep(bool has_dir, bool has_q, const SweepArgs &a, const LineGeom &g, long inner_stride, const SweepScal &s,
+                   double *out, const double *xlo, const double *xhi, double *wc, double *wd, hipStream_t st);
+// adi_condense.hip: pass A of a sweep whose lines span several slabs
+int condense_sweep(bool has_dir, bool has_q, int axis, const SweepArgs &a, const Lay &L, const SweepScal &s, double *cond,
+                   void *work, size_t work_bytes, hipStream_t st, const Fuse *fz);
+void condense_generic_lines(bool has_dir, bool has_q, const SweepArgs &a, const Lay &L, const SweepScal &s, double *cond,
+                            const unsigned *list, long line_begin, long nsel, hipStream_t st);
+
+}  // namespace adi

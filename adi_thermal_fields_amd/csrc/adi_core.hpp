@@ -138,6 +138,8 @@ __device__ __forceinline__ void back_solve(const double (&a)[M], const double (&
 // exposed cell with a Robin coefficient) is Uint + delta e0 e0^T and is handled branch-free by
 // Sherman-Morrison:  A^-1 r = P r - kappa (p.r) p,  kappa = delta / (1 + delta p_0).
 // Replaces 2*(M-1) reciprocal chains by two dot products with constants.
+// The helpers below take the constants as any type UC with members s, bu, p[], w[], ip[] (UniC<M> in scalar registers;
+// the marching fused kernel passes a view of a copy in LDS for its rare surface lanes).
 template <int M>
 struct UniC {
     double s, bu;
@@ -146,8 +148,8 @@ struct UniC {
     double ip[M - 1];   // inverse pivots of the uniform Thomas factorisation
 };
 
-template <int M>
-__device__ __forceinline__ void condense_uniform(const UniC<M> &U, double a0, double b0, const double (&d)[M],
+template <int M, class UC>
+__device__ __forceinline__ void condense_uniform(const UC &U, double a0, double b0, const double (&d)[M],
                                                  Cond &k, double &kappa)
 {
     constexpr int MI = M - 1;
@@ -171,8 +173,8 @@ __device__ __forceinline__ void condense_uniform(const UniC<M> &U, double a0, do
 }
 
 // in place: on entry d = right-hand sides of the M rows, on exit d = solution (row M-1 = xS)
-template <int M>
-__device__ __forceinline__ void back_solve_uniform(const UniC<M> &U, double a0, double kappa, double (&d)[M],
+template <int M, class UC>
+__device__ __forceinline__ void back_solve_uniform(const UC &U, double a0, double kappa, double (&d)[M],
                                                    double xL, double xS)
 {
     constexpr int MI = M - 1;
@@ -201,8 +203,8 @@ template <int M, bool REV>
 __device__ __forceinline__ double &mixed_row(double (&d)[M], int q) { return d[REV ? (M - 2 - q) : q]; }
 
 // x_(q=0) = G - A * x_out  (elimination from the modified end towards the coupled end; O(1) state)
-template <int M, bool REV>
-__device__ __forceinline__ void mixed_condense(const UniC<M> &U, double (&d)[M], int L, double bmod, double a_c,
+template <int M, bool REV, class UC>
+__device__ __forceinline__ void mixed_condense(const UC &U, double (&d)[M], int L, double bmod, double a_c,
                                                double &G, double &A)
 {
     constexpr int MI = M - 1;
@@ -224,8 +226,8 @@ __device__ __forceinline__ void mixed_condense(const UniC<M> &U, double (&d)[M],
 
 // in place: rows of the run <- solution, given the outside unknown; Thomas from the coupled end with the prefix
 // factors of the uniform block (w, ip) and one modified pivot at the far end
-template <int M, bool REV>
-__device__ __forceinline__ void mixed_back_solve(const UniC<M> &U, double (&d)[M], int L, double bmod, double a_c,
+template <int M, bool REV, class UC>
+__device__ __forceinline__ void mixed_back_solve(const UC &U, double (&d)[M], int L, double bmod, double a_c,
                                                  double x_out)
 {
     constexpr int MI = M - 1;
@@ -259,8 +261,8 @@ __device__ __forceinline__ void mixed_back_solve(const UniC<M> &U, double (&d)[M
 // even rows are kept in 8 registers addressed by (row >> 1) & 7, unique inside a run of at most 16 rows; the back
 // substitution recomputes the pivot of an odd row from its even predecessor with the same operations (bit-identical).
 // bS / bE: diagonals of the first / last row of the run (line start / line end; bS alone when L == 1).
-template <int M>
-__device__ __forceinline__ void island_solve(const UniC<M> &U, double (&d)[M], int m, int L, double bS, double bE)
+template <int M, class UC>
+__device__ __forceinline__ void island_solve(const UC &U, double (&d)[M], int m, int L, double bS, double bE)
 {
     constexpr int MI = M - 1;
     const int e = m + L;

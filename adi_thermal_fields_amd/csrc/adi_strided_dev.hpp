@@ -1,0 +1,271 @@
+// adi_strided_dev.hpp -- segment loaders of the strided-axis kernels (sweeps along memory axes 0 and 1, and the slab
+// condensation that shares their loads).  See adi_sweep_strided.hip for the tiling.
+#pragma once
+#include "adi_cart_dev.hpp"
+
+namespace adi {
+
+template <int M>
+struct SegRaw {
+    double vin[M], vco[M], vdv[M], vq[M];
+    unsigned fb[M];
+    bool dirb[M];
+};
+
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
+__device__ __forceinline__ void load_segment_raw(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    const LineGeom &g, long base, int r0, bool active, const SweepScal &s, SegRaw<M> &R, const Fuse &fz = Fuse())
+{
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        const bool ok = active && (r0 + r) < g.n;
+        const long p = base + (long)(r0 + r) * g.stride;
+        R.fb[r] = ok ? flags[p] : 0u;
+        R.vin[r] = ok ? in[p] : 0.0;
+    }
+    if (FUSE) {
+        // vin <- R0 of the explicit stage; every neighbour is loaded only where the flags byte says it exists
+        // (rows beyond the line / inactive lanes have flags 0 and stay 0)
+        double prev = 0.0;
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            const long p = base + (long)(r0 + r) * g.stride;
+            const unsigned f = R.fb[r];
+            const double cur = R.vin[r];
+            double im, ip;
+            if (r > 0) im = prev; else im = (f & 2u) ? in[p - g.stride] : 0.0;
+            if (r < M - 1 && r0 + r + 1 < g.n) ip = R.vin[r + 1];   // still the state: rows are overwritten in order
+            else ip = (f & 4u) ? in[p + g.stride] : 0.0;             // next segment / halo plane of a slab
+            const double jm = (f & 8u) ? in[p - fz.sy] : 0.0, jp = (f & 16u) ? in[p + fz.sy] : 0.0;
+            const double km = (f & 32u) ? in[p - 1] : 0.0, kp = (f & 64u) ? in[p + 1] : 0.0;
+            R.vin[r] = explicit_cell(f, cur, im, ip, jm, jp, km, kp, fz);
+            prev = cur;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        const bool ok = active && (r0 + r) < g.n;
+        const long p = base + (long)(r0 + r) * g.stride;
+        const bool need = ok && (!s.sparse || axis_exposed(R.fb[r], g.lbit));
+        R.dirb[r] = false;
+        if (HAS_DIR) R.dirb[r] = ok && dmask[p] != 0;
+        R.vco[r] = need ? coeff[p] : 0.0;
+        R.vq[r] = (HAS_Q && need) ? qf[p] : 0.0;
+        R.vdv[r] = (HAS_DIR && ok && (!s.sparse || R.dirb[r])) ? dval[p] : 0.0;
+    }
+}
+
+template <int M, bool HAS_DIR, bool HAS_Q>
+__device__ __forceinline__ void assemble_one(const SegRaw<M> &R, int r, int lbit, const SweepScal &s, double &a,
+                                             double &b, double &c, double &d)
+{
+    assemble_row<HAS_DIR, HAS_Q>(R.fb[r] & 1u, (R.fb[r] >> lbit) & 1u, (R.fb[r] >> (lbit + 1)) & 1u, R.dirb[r],
+                                 R.vin[r], R.vco[r], R.vdv[r], R.vq[r], s, a, b, c, d);
+}
+
+
+// FAST strided kernels, part 1: load the segment's `in` rows and classify it.  Only the flags of row 0 and of the
+// separator row are kept (the interior rows just have to be uniform).
+// Addressing: element (row sg*M + r, column kcol) = [tile base + r*stride] (block-uniform -> scalar registers)
+//             + voff, voff = sg*M*stride + kk a per-thread 32-bit offset that is the same for every row and array.
+template <int M, bool HAS_DIR>
+__device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in_t, const uint8_t *__restrict__ flags_t,
+                                                  const uint8_t *__restrict__ dmask_t, const LineGeom &g, unsigned voff,
+                                                  int r0, bool active, double (&d)[M], unsigned &f0, unsigned &fS,
+                                                  bool &dirS, int &kind, int &Lm)
+{
+    // kind: the segment class (SEG_*): a padding segment (r0 >= n: the line has fewer than Lp segments) owns no rows, a
+    // segment whose rows are all outside the mask is M identity rows, TAIL / HEAD are crossed by the surface once
+    const bool pad = active && r0 >= g.n;
+    bool uni = active && (r0 + M <= g.n);
+    const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
+    f0 = 0; fS = 0;
+    unsigned inm = 0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        const bool ok = active && (r0 + r) < g.n;
+        const unsigned f = ok ? (flags_t + (size_t)r * g.stride)[voff] : 0u;
+        d[r] = ok ? (in_t + (size_t)r * g.stride)[voff] : 0.0;
+        inm |= (f & 1u) << r;
+        if (r == 0) { f0 = f; uni = uni && ((f & ROW0) == ROW0); }
+        else if (r == M - 1) fS = f;
+        else uni = uni && ((f & FULL) == FULL);
+    }
+    bool nodir = true;
+    dirS = false;
+    if (HAS_DIR) {
+#pragma unroll
+        for (int r = 0; r < M - 1; ++r)
+            nodir = nodir && (pad || inm == 0u || (dmask_t + (size_t)r * g.stride)[voff] == 0);
+        dirS = active && inm != 0u && (r0 + M - 1) < g.n && (dmask_t + (size_t)(M - 1) * g.stride)[voff] != 0;
+    }
+    Lm = 0;
+    if (pad) kind = SEG_PAD;
+    else if (!active || r0 + M > g.n) kind = SEG_NONE;
+    else if (uni) kind = nodir ? SEG_UNI : SEG_NONE;
+    else {
+        kind = classify_mixed<M>(inm, f0, g.lbit, Lm);
+        if (kind >= SEG_TAIL && !nodir) kind = SEG_NONE;
+    }
+    return kind != SEG_NONE;
+}
+
+// The same for whole tiles (block-uniform precondition: every lane active, every thread owns M rows), buffer
+// addressing: scalar row offsets, one per-thread offset, no per-row predicates and no 64-bit address arithmetic.
+template <int M, bool HAS_DIR>
+__device__ __forceinline__ bool fast_segment_load_buf(const double *__restrict__ in_t, const uint8_t *__restrict__ flags_t,
+                                                      const uint8_t *__restrict__ dmask_t, const LineGeom &g, unsigned voff,
+                                                      double (&d)[M], unsigned &f0, unsigned &fS, bool &dirS, int &kind,
+                                                      int &Lm)
+{
+    const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void *)in_t, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void *)flags_t, 0, 0x7fffffff, 0x00020000);
+    const unsigned st = (unsigned)g.stride;
+    bool uni = true;
+    unsigned inm = 0;
+    f0 = 0; fS = 0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        const unsigned f = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, ADI_LOAD_AUX);
+        d[r] = buf_load_f64_once(rT, voff * 8u, (unsigned)r * st * 8u);
+        inm |= (f & 1u) << r;
+        if (r == 0) { f0 = f; uni = uni && ((f & ROW0) == ROW0); }
+        else if (r == M - 1) fS = f;
+        else uni = uni && ((f & FULL) == FULL);
+    }
+    bool nodir = true;
+    dirS = false;
+    if (HAS_DIR) {
+        const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void *)dmask_t, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < M - 1; ++r)
+            nodir = nodir && (inm == 0u || __builtin_amdgcn_raw_buffer_load_b8(rD, voff, (unsigned)r * st, 0) == 0);
+        dirS = inm != 0u && __builtin_amdgcn_raw_buffer_load_b8(rD, voff, (unsigned)(M - 1) * st, 0) != 0;
+    }
+    Lm = 0;
+    if (uni) kind = nodir ? SEG_UNI : SEG_NONE;
+    else {
+        kind = classify_mixed<M>(inm, f0, g.lbit, Lm);
+        if (kind >= SEG_TAIL && !nodir) kind = SEG_NONE;
+    }
+    return kind != SEG_NONE;
+}
+
+// The same with the explicit stage folded in (FUSE kernels): d <- R0 = T + f*(Lx+Ly+Lz) of this thread's M rows.
+// Preconditions (block-uniform, checked by the caller): the tile is whole -- LINES == 16 active lines, every thread owns
+// M rows of the line (Lp*M == n) -- so no load needs a per-row predicate.  Neighbour loads do not wait for the flags:
+// an address is read whenever it lies inside [vlo, vhi) and the value is used only where the flags byte says the
+// neighbour exists; only the first row of a line can fall below vlo and only the last row above vhi.
+// A 16-lane DPP row = the 16 lines of one segment: k-neighbours come from the adjacent lanes (row_shr/row_shl), the two
+// outside the tile are loaded transposed (lane kk fetches the pair of row kk) and handed to lanes 0 / 15 with
+// row_newbcast as the `old` operand of the shift, which is what the out-of-row lane keeps.
+template <int M, bool HAS_DIR, bool MIXED = true>
+__device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict__ in, const uint8_t *__restrict__ flags_t,
+                                                        const uint8_t *__restrict__ dmask_t, const LineGeom &g,
+                                                        unsigned voff, int r0, int kk, long tbase, const Fuse &fz,
+                                                        double (&d)[M], unsigned &f0, unsigned &fS, bool &dirS, int &kind,
+                                                        int &Lm)
+{
+#pragma clang fp contract(off)
+    constexpr int LINES = 16;
+    const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
+    // the state through a descriptor over the window [wlo, wlo + wbytes/8) of `in` (host: covers every neighbour of
+    // the box that exists in memory, < 4 GiB); flags through one based at the tile
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void *)(in + fz.wlo), 0, (int)fz.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void *)flags_t, 0, 0x7fffffff, 0x00020000);
+    const unsigned vb = voff * 8u;                                   // this thread's row 0, bytes from the tile base
+    const unsigned R0 = (unsigned)((tbase - fz.wlo) * 8);            // tile base, bytes from the window start (scalar)
+    const unsigned st8 = (unsigned)(g.stride * 8), sy8 = (unsigned)(fz.sy * 8);
+    // Every load below is unconditional.  Rows whose neighbour always lies inside the window take the scalar row offset;
+    // the few that can fall outside it (first row: i-1, j-1, k0-1; last row: i+1, j+1, k0+16) carry the whole offset in
+    // the per-thread register, where the descriptor's range check turns an address before or after the window into a
+    // load of 0 -- such a neighbour does not exist and the flags byte says so.
+    unsigned fb[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        fb[r] = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * (unsigned)g.stride, ADI_LOAD_AUX);
+        d[r] = buf_load_f64(rT, vb, R0 + (unsigned)r * st8);
+    }
+    const unsigned vw = vb + R0;                                     // this thread's row 0, bytes from the window start
+    const unsigned vl = vw + (unsigned)(M - 1) * st8;                // its last row
+    const double tim = buf_load_f64(rT, vw - st8, 0u);
+    const double tip = buf_load_f64(rT, vl + st8, 0u);
+    // k-neighbours outside the tile, loaded transposed: lane kk fetches the pair of row kk (columns k0-1, k0+16)
+    const unsigned ve = R0 + (unsigned)(r0 + (int)(threadIdx.x & 15u)) * st8;
+    const double eL = buf_load_f64(rT, ve - 8u, 0u);
+    const double eR = buf_load_f64(rT, ve + LINES * 8u, 0u);
+    bool uni = true, full = true;
+    unsigned inm = 0;                               // MIXED: bit r = row r in the mask; otherwise just "any row in the mask"
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        full = full && (fb[r] == 0x7fu);
+        if (MIXED) inm |= (fb[r] & 1u) << r;
+        else inm |= fb[r];
+        if (r == 0) uni = uni && ((fb[r] & ROW0) == ROW0);
+        else if (r < M - 1) uni = uni && ((fb[r] & FULL) == FULL);
+    }
+    if (!MIXED) inm &= 1u;
+    f0 = fb[0]; fS = fb[M - 1];
+    const bool wave_full = __all(full);                     // every cell of this wave has its six neighbours
+    // j-neighbour rows: a software pipeline D rows deep (they are L2 hits -- the tiles of the adjacent j-rows run next
+    // door on the same XCD -- so a short pipeline covers their latency; a register pair per row in flight).  The
+    // sched_barriers pin the order: without them the scheduler hoists every load to the top and spills.
+    constexpr int D = (M >= 8) ? ADI_FUSE_D : M;
+    auto load_jm = [&](int r) -> double {
+        return (r == 0) ? buf_load_f64(rT, vw - sy8, 0u) : buf_load_f64(rT, vb, R0 + (unsigned)r * st8 - sy8);
+    };
+    auto load_jp = [&](int r) -> double {
+        return (r == M - 1) ? buf_load_f64(rT, vl + sy8, 0u) : buf_load_f64(rT, vb, R0 + (unsigned)r * st8 + sy8);
+    };
+    double hm[D], hp[D];
+#pragma unroll
+    for (int q = 0; q < D; ++q) { hm[q] = load_jm(q); hp[q] = load_jp(q); }
+    double prev = tim;
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        __builtin_amdgcn_sched_barrier(0);
+        const double cur = d[r];
+        const double nxt = (r < M - 1) ? d[r + 1] : tip;     // still the state: rows are overwritten in order
+        const double jm = hm[r % D], jp = hp[r % D];
+        const double km = dpp_mov<0x111>(row_bcast(eL, r), cur), kp = dpp_mov<0x101>(row_bcast(eR, r), cur);
+        if (wave_full) {
+            // lap_axis with both neighbours present, same operation order: ((0 + lo) + hi - 2*t) * invdx2
+            const double c2 = 2.0 * cur;
+            const double L0 = (((0.0 + prev) + nxt) - c2) * fz.invdx2;
+            const double L1 = (((0.0 + jm) + jp) - c2) * fz.invdx2;
+            const double L2 = (((0.0 + km) + kp) - c2) * fz.invdx2;
+            d[r] = cur + fz.f * ((L0 + L1) + L2);
+        } else {
+            d[r] = explicit_cell(fb[r], cur, prev, nxt, jm, jp, km, kp, fz);
+        }
+        prev = cur;
+        if (r + D < M) {
+            __builtin_amdgcn_sched_barrier(0);
+            hm[r % D] = load_jm(r + D); hp[r % D] = load_jp(r + D);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bool nodir = true;
+    dirS = false;
+    if (HAS_DIR) {
+#pragma unroll
+        for (int r = 0; r < M - 1; ++r)
+            nodir = nodir && (inm == 0u || (dmask_t + (size_t)r * g.stride)[voff] == 0);
+        dirS = inm != 0u && (dmask_t + (size_t)(M - 1) * g.stride)[voff] != 0;
+    }
+    Lm = 0;
+    if (uni) kind = nodir ? SEG_UNI : SEG_NONE;
+    else if (!MIXED) kind = (inm == 0u) ? SEG_OFF : SEG_NONE;
+    else {
+        kind = classify_mixed<M>(inm, f0, g.lbit, Lm);     // rows outside the mask have R0 = T: identity rows
+        if (kind >= SEG_TAIL && !nodir) kind = SEG_NONE;
+    }
+    return kind != SEG_NONE;
+}
+
+// FAST kernel (sparse packs): tiles whose every segment is uniform-interior (see k_sweep_contig_fast)
+
+}  // namespace adi

@@ -1,0 +1,330 @@
+// adi_sweep_strided.hip -- K2: the batched tridiagonal sweeps along the strided axes (memory axes 0 and 1): sweep_axis0/1
+// + thomas_solve of adi3d_numba_coeff.py:133-202, :121-130 (identity-row form of adi3d_gpu_coeff.py:154-191), the form
+// with the explicit stage (lap1D_x/y/z + R0, :240-298) folded into the loads of the axis-0 sweep, and K4, the
+// thread-per-line sweep for lines beyond 1024 rows.  Hand-written HIP for gfx950; HBM-bound, no MFMA.
+#include "adi_cart_host.hpp"
+#include "adi_strided_dev.hpp"
+
+namespace adi {
+
+// ------------------------------------------------------------------------------------------------
+// K2: strided-axis sweep.  A workgroup owns a tile of LINES adjacent lines and all Lp segments of each;
+// thread (sg, kk) keeps the M rows of segment sg of line kk in registers (lanes run along the contiguous
+// direction, so every access is coalesced without a transpose).  Only the 7 condensation numbers per
+// segment travel through LDS to regroup the separator system line-major for the in-wave PCR, and the
+// separator values travel back.  LINES = 8 (64-byte row pieces, 512-thread workgroups, two per CU so one
+// loads while the other solves); the XCD-chunked tile order puts the tile holding the other half of each
+// 128-byte line on the same XCD right behind it, so the half-line is served by that XCD's L2.
+//
+// Lines geometry: element (row r, line (to, kcol)) lives at to*outer_stride + r*stride + kcol.
+// xlo/xhi (optional, dense per line): values of the unknown just before row 0 / after row n-1 when the line
+// continues on a neighbouring GPU; the coupling itself comes from the halo bits of `flags`.
+// ------------------------------------------------------------------------------------------------
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
+__device__ __forceinline__ void strided_tile_general(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ out, const LineGeom &g, int Lp, int LINES, int tiles_inner, long tile,
+    const double *__restrict__ xlo, const double *__restrict__ xhi, const SweepScal &s, double *sm,
+    const Fuse &fz = Fuse())
+{
+    const int tid = threadIdx.x;
+    const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
+    const int ti = (int)(tile - to * tiles_inner);
+    const int kk = tid & (LINES - 1), sg = tid >> (__ffs(LINES) - 1);   // LINES is a power of two
+    const int kcol = ti * LINES + kk;
+    const bool active = kcol < g.n_inner;
+    const long base = to * g.outer_stride + kcol;
+    const int r0 = sg * M;
+    const long line_id = to * (long)g.n_inner + kcol;
+
+    double a[M], b[M], c[M], d[M];
+    {
+        SegRaw<M> R;
+        load_segment_raw<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R, fz);
+#pragma unroll
+        for (int r = 0; r < M; ++r) assemble_one<M, HAS_DIR, HAS_Q>(R, r, g.lbit, s, a[r], b[r], c[r], d[r]);
+    }
+    // line ends: fold the coupling to the neighbouring GPU's row into the right-hand side
+    if (r0 == 0) {
+        if (xlo != nullptr && active) d[0] = __builtin_fma(-a[0], xlo[line_id], d[0]);
+        a[0] = 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+        if (r0 + r == g.n - 1) {
+            if (xhi != nullptr && active) d[r] = __builtin_fma(-c[r], xhi[line_id], d[r]);
+            c[r] = 0.0;
+        }
+    double ip[M - 1];
+    Cond k;
+    condense<M>(a, b, c, d, ip, k);
+    double xL, xS;
+    tile_separators(sm, tid, kk, sg, Lp, LINES, a[M - 1], b[M - 1], c[M - 1], d[M - 1], k, xL, xS);
+    double x[M];
+    back_solve<M>(a, c, d, ip, xL, xS, x);
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+        if (active && (r0 + r) < g.n) out[base + (long)(r0 + r) * g.stride] = x[r];
+}
+
+// GENERAL kernel: every tile (queue == nullptr) or the tiles a FAST kernel queued
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
+__global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ out, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
+    const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s, const unsigned *__restrict__ queue,
+    int ratio, int tiles_inner_f, Fuse fz)
+{
+    extern __shared__ __align__(16) double sm[];
+    if (queue == nullptr) {
+        strided_tile_general<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, out, g, Lp, LINES, tiles_inner,
+                                                      xcd_chunk_tile(blockIdx.x, ntiles), xlo, xhi, s, sm, fz);
+    } else {
+        // a queued unit is a tile of the FAST kernel = `ratio` adjacent tiles of this kernel
+        const long cnt = (long)queue[0] * ratio;
+        for (long i = blockIdx.x; i < cnt; i += gridDim.x) {
+            const long u = queue[1 + (unsigned)i / (unsigned)ratio];
+            const long to = (long)((unsigned)u / (unsigned)tiles_inner_f);
+            const long tig = (u - to * tiles_inner_f) * ratio + ((unsigned)i % (unsigned)ratio);
+            if (tig < tiles_inner)
+                strided_tile_general<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, out, g, Lp, LINES,
+                                                              tiles_inner, to * tiles_inner + tig, xlo, xhi, s, sm, fz);
+            __syncthreads();   // the LDS arrays are reused by the next tile
+        }
+    }
+}
+
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false, bool MIXED = true>
+__global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_fast(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ out, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
+    const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s, unsigned *__restrict__ queue,
+    UniC<M> U, Fuse fz)
+{
+    extern __shared__ __align__(16) double sm[];
+    const int tid = threadIdx.x;
+    long tile = xcd_chunk_tile(blockIdx.x, ntiles);
+    if (FUSE && fz.kg > 0) tile = tile_jfast(tile, fz);
+    const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
+    const int ti = (int)(tile - to * tiles_inner);
+    const int kk = tid & (LINES - 1), sg = tid >> (__ffs(LINES) - 1);   // LINES is a power of two
+    const int kcol = ti * LINES + kk;
+    const bool active = kcol < g.n_inner;
+    const long base = to * g.outer_stride + kcol;
+    const int r0 = sg * M;
+    const long line_id = to * (long)g.n_inner + kcol;
+
+    double d[M];
+    unsigned f0, fS;
+    bool dirS;
+    // block-uniform tile base (scalar) + one 32-bit per-thread offset for every row of every array
+    const long tbase = to * g.outer_stride + (long)ti * LINES;
+    const unsigned voff = (unsigned)((long)r0 * g.stride + kk);
+    const bool pad = r0 >= g.n;                    // this thread's segment lies beyond the end of the line
+    int kind = SEG_NONE, Lm = 0;                   // segment class (classify_mixed) and length of a mixed run
+    bool lane_fast;
+    if constexpr (FUSE) {
+        // whole tiles only (block-uniform): anything else goes to the GENERAL kernel before a single load is issued
+        if (LINES != 16 || (ti + 1) * LINES > g.n_inner || g.n % M != 0) {
+            if (tid == 0) enqueue_unit(queue, (unsigned)tile);
+            return;
+        }
+        // a padding segment (line with fewer than Lp segments) re-reads segment 0 -- valid addresses, values unused
+        const int r0e = pad ? 0 : r0;
+        lane_fast = fast_segment_load_fused<M, HAS_DIR, MIXED>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g,
+                                                               pad ? (unsigned)kk : voff, r0e, kk, tbase, fz, d, f0, fS, dirS,
+                                                               kind, Lm) || pad;
+        if (pad) kind = SEG_PAD;
+    } else {
+        // whole tiles whose rows fit 31-bit byte offsets take the buffer-addressed loader (block-uniform choice)
+        const bool whole = kBufStrided && (ti + 1) * LINES <= g.n_inner && Lp * M == g.n &&
+                           (long)g.n * g.stride * 8 < 0x7fffffffL;
+        if (whole)
+            lane_fast = fast_segment_load_buf<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, d,
+                                                          f0, fS, dirS, kind, Lm);
+        else
+            lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
+                                                      active, d, f0, fS, dirS, kind, Lm);
+    }
+    if (pad) { f0 = 0; fS = 0; dirS = false; }       // (the fused loader showed a padding thread segment 0's flags)
+    if (!MIXED && kind >= SEG_TAIL) lane_fast = false;
+    if (!__syncthreads_and(lane_fast)) {
+        if (tid == 0) enqueue_unit(queue, (unsigned)tile);
+        return;
+    }
+    double a0, b0, aS, bS, cS;
+    fast_segment_ends<M, HAS_DIR, HAS_Q>(coeff, dval, qf, g, base, r0, f0, fS, dirS, s, d, a0, b0, aS, bS, cS);
+    if (r0 == 0) {
+        if (xlo != nullptr) d[0] = __builtin_fma(-a0, xlo[line_id], d[0]);
+        a0 = 0.0;
+    }
+    if (r0 + M == g.n) {
+        if (xhi != nullptr) d[M - 1] = __builtin_fma(-cS, xhi[line_id], d[M - 1]);
+        cS = 0.0;
+    }
+    Cond k;
+    double kappa;
+    condense_uniform<M>(U, a0, b0, d, k, kappa);
+    const bool off = kind == SEG_OFF;              // a segment outside the mask: identity rows, x = in
+    if (pad || off) {                              // identity block: nothing reaches the real segments
+        k.gF = k.aF = k.cF = k.gL = k.aL = k.cL = 0.0;
+        kappa = 0.0; aS = 0.0; bS = 1.0; cS = 0.0;
+        if (pad) d[M - 1] = 0.0;
+    }
+    double2 bmod = make_double2(1.0, 1.0);
+    if constexpr (MIXED) {
+        if (kind >= SEG_TAIL)                      // the surface crosses the segment once (adi_core.hpp, mixed_*)
+            mixed_lane_condense<M, HAS_Q>(kind, Lm, U, s, coeff + base + (long)r0 * g.stride,
+                                          HAS_Q ? qf + base + (long)r0 * g.stride : qf, g.stride, a0, b0, d, bmod, k);
+    }
+    double xL, xS;
+    tile_separators(sm, tid, kk, sg, Lp, LINES, aS, bS, cS, d[M - 1], k, xL, xS);
+    if (kind == SEG_UNI || kind == SEG_PAD) back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
+    else if constexpr (MIXED) {
+        if (kind >= SEG_TAIL) mixed_lane_back_solve<M>(kind, Lm, U, bmod, a0, d, xL, xS);
+    }
+    if (pad) return;                               // (after the last barrier)
+    double *out_t = out + tbase;
+    if (FUSE || (kBufStrided && (long)g.n * g.stride * 8 < 0x7fffffffL)) {
+        const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)out_t, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < M; ++r) buf_store_f64(rO, voff * 8u, (unsigned)r * (unsigned)(g.stride * 8), d[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < M; ++r) (out_t + (size_t)r * g.stride)[voff] = d[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: generic fallback, one thread per line, normalised Thomas (adi3d_gpu_coeff.py:140-152) with the
+// forward-pass c', d' kept in an HBM workspace.  Used only for lines longer than kMaxFastLine rows.
+// ------------------------------------------------------------------------------------------------
+template <bool HAS_DIR, bool HAS_Q>
+__global__ __launch_bounds__(256) void k_sweep_generic(
+    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
+    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
+    double *__restrict__ out, LineGeom g, long inner_stride, const double *__restrict__ xlo,
+    const double *__restrict__ xhi, double *__restrict__ wc, double *__restrict__ wd, SweepScal s)
+{
+    const long lid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lid >= (long)g.n_inner * g.n_outer) return;
+    const long o = lid / g.n_inner, kc = lid - o * g.n_inner;
+    const long base = o * g.outer_stride + kc * inner_stride;
+    const int n = g.n;
+    double cp = 0.0, dp = 0.0;
+    for (int r = 0; r < n; ++r) {
+        const long p = base + (long)r * g.stride;
+        const unsigned f = flags[p];
+        double a, b, c, d;
+        assemble_row<HAS_DIR, HAS_Q>(f & 1u, (f >> g.lbit) & 1u, (f >> (g.lbit + 1)) & 1u, HAS_DIR && dmask[p] != 0, in[p],
+                                     coeff[p], HAS_DIR ? dval[p] : 0.0, HAS_Q ? qf[p] : 0.0, s, a, b, c, d);
+        if (r == 0) { if (xlo != nullptr) d -= a * xlo[lid]; a = 0.0; }
+        if (r == n - 1) { if (xhi != nullptr) d -= c * xhi[lid]; c = 0.0; }
+        const double inv = 1.0 / (b - a * cp);
+        cp = c * inv;
+        dp = (d - a * dp) * inv;
+        wc[p] = cp;
+        wd[p] = dp;
+    }
+    double x = 0.0;
+    for (int r = n - 1; r >= 0; --r) {
+        const long p = base + (long)r * g.stride;
+        x = wd[p] - wc[p] * x;
+        out[p] = x;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// host-side launch logic
+// ------------------------------------------------------------------------------------------------
+template <int MF, bool HAS_DIR, bool HAS_Q, bool FUSE>
+static void launch_strided_fast(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
+                                const uint8_t *dmask, const double *dval, const double *qf, double *out,
+                                const LineGeom &g, const double *xlo, const double *xhi, SweepScal s, unsigned *queue,
+                                hipStream_t st, const Fuse &fz)
+{
+    if (s.box && MF <= 16) // all-solid box (caller's hint): the build without surface-segment lanes (fused: no spills)
+        hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE, (MF > 16)>), dim3((unsigned)P.ntiles_f),
+                           dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
+                           P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
+    else
+        hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE, true>), dim3((unsigned)P.ntiles_f),
+                           dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
+                           P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
+}
+
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE>
+static void launch_strided(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
+                           const uint8_t *dmask, const double *dval, const double *qf, double *out, const LineGeom &g,
+                           const double *xlo, const double *xhi, SweepScal s, unsigned *queue, hipStream_t st,
+                           const Fuse &fz)
+{
+    unsigned ggrid = (unsigned)P.ntiles_g;
+    if (queue != nullptr) {
+        (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
+        if (P.Mf == 32) launch_strided_fast<32, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
+        else if (P.Mf == 16) launch_strided_fast<16, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
+        else launch_strided_fast<8, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
+        ggrid = P.ntiles_g < 1024 ? (unsigned)P.ntiles_g : 1024u;
+    }
+    hipLaunchKernelGGL((k_sweep_strided<M, HAS_DIR, HAS_Q, FUSE>), dim3(ggrid), dim3(P.lines_g * P.Lpg), P.lds_g, st, in,
+                       flags, coeff, dmask, dval, qf, out, g, P.Lpg, P.lines_g, P.tiles_inner_g, P.ntiles_g, xlo, xhi,
+                       s, queue, P.ratio, P.tiles_inner_f, fz);
+}
+
+template <bool HAS_DIR, bool HAS_Q>
+static void strided_sweep_t(const SweepArgs &a, const Lay &L, const LineGeom &g, const SweepScal &s, double *out,
+                            const double *xlo, const double *xhi, void *work, size_t work_bytes, hipStream_t st,
+                            const Fuse *fzp)
+{
+    StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr, false, fzp != nullptr);
+    unsigned *queue = nullptr;
+    if (P.Mf && use_fast(s, work, work_bytes, P.ntiles_f)) queue = (unsigned *)work;
+    else if (P.Mf) P = strided_plan(g, false, false);
+    if (fzp != nullptr) {
+        Fuse fz = *fzp;
+        if (queue != nullptr && !fuse_fast_ok(P, L, fz)) { queue = nullptr; P = strided_plan(g, false, false); }
+        fuse_tile_order(fz, P, L);
+        switch (P.Mg) {
+            case 2: launch_strided<2, HAS_DIR, HAS_Q, true>(P, a.in, a.flags, a.coeff, a.dmask, a.dval, a.qf, out, g, xlo, xhi, s, queue, st, fz); break;
+            case 4: launch_strided<4, HAS_DIR, HAS_Q, true>(P, a.in, a.flags, a.coeff, a.dmask, a.dval, a.qf, out, g, xlo, xhi, s, queue, st, fz); break;
+            case 8: launch_strided<8, HAS_DIR, HAS_Q, true>(P, a.in, a.flags, a.coeff, a.dmask, a.dval, a.qf, out, g, xlo, xhi, s, queue, st, fz); break;
+            default: launch_strided<16, HAS_DIR, HAS_Q, true>(P, a.in, a.flags, a.coeff, a.dmask, a.dval, a.qf, out, g, xlo, xhi, s, queue, st, fz); break;
+        }
+        return;
+    }
+    const Fuse fz = Fuse();
+    switch (P.Mg) {
+        case 2: launch_strided<2, HAS_DIR, HAS_Q, false>(P, a.in, a.flags, a.coeff, a.dmask, a.dval, a.qf, out, g, xlo, xhi, s, queue, st, fz); break;
+        case 4: launch_strided<4, HAS_DIR, HAS_Q, false>(P, a.in, a.flags, a.coeff, a.dmask, a.dval, a.qf, out, g, xlo, xhi, s, queue, st, fz); break;
+        case 8: launch_strided<8, HAS_DIR, HAS_Q, false>(P, a.in, a.flags, a.coeff, a.dmask, a.dval, a.qf, out, g, xlo, xhi, s, queue, st, fz); break;
+        default: launch_strided<16, HAS_DIR, HAS_Q, false>(P, a.in, a.flags, a.coeff, a.dmask, a.dval, a.qf, out, g, xlo, xhi, s, queue, st, fz); break;
+    }
+}
+
+void strided_sweep(bool has_dir, bool has_q, const SweepArgs &a, const Lay &L, const LineGeom &g, const SweepScal &s,
+                   double *out, const double *xlo, const double *xhi, void *work, size_t work_bytes, hipStream_t st,
+                   const Fuse *fz)
+{
+    if (has_dir && has_q) strided_sweep_t<true, true>(a, L, g, s, out, xlo, xhi, work, work_bytes, st, fz);
+    else if (has_q) strided_sweep_t<false, true>(a, L, g, s, out, xlo, xhi, work, work_bytes, st, fz);
+    else if (has_dir) strided_sweep_t<true, false>(a, L, g, s, out, xlo, xhi, work, work_bytes, st, fz);
+    else strided_sweep_t<false, false>(a, L, g, s, out, xlo, xhi, work, work_bytes, st, fz);
+}
+
+void generic_sweep(bool has_dir, bool has_q, const SweepArgs &a, const LineGeom &g, long inner_stride, const SweepScal &s,
+                   double *out, const double *xlo, const double *xhi, double *wc, double *wd, hipStream_t st)
+{
+    const long nl = (long)g.n_inner * g.n_outer;
+    const dim3 grid((unsigned)((nl + 255) / 256)), block(256);
+    if (has_dir && has_q) hipLaunchKernelGGL((k_sweep_generic<true, true>), grid, block, 0, st, a.in, a.flags, a.coeff, a.dmask, a.dval, a.qf, out, g, inner_stride, xlo, xhi, wc, wd, s);
+    else if (has_q) hipLaunchKernelGGL((k_sweep_generic<false, true>), grid, block, 0, st, a.in, a.flags, a.coeff, a.dmask, a.dval, a.qf, out, g, inner_stride, xlo, xhi, wc, wd, s);
+    else if (has_dir) hipLaunchKernelGGL((k_sweep_generic<true, false>), grid, block, 0, st, a.in, a.flags, a.coeff, a.dmask, a.dval, a.qf, out, g, inner_stride, xlo, xhi, wc, wd, s);
+    else hipLaunchKernelGGL((k_sweep_generic<false, false>), grid, block, 0, st, a.in, a.flags, a.coeff, a.dmask, a.dval, a.qf, out, g, inner_stride, xlo, xhi, wc, wd, s);
+}
+
+}  // namespace adi

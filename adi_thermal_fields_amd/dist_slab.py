@@ -344,9 +344,11 @@ class SlabStepper:
         self.Lint = E.layout(self.nxl, self.ny, self.nz)
         assert self.Lint.sx == self.Lext.sx
         self.nlines = self.ny * self.nz
-        self._ext_bufs = [self.Lext.empty(), self.Lext.empty()]
+        # zero-filled once: the outer halo planes of the first / last rank and the padded tail of every plane are never
+        # written; the kernels read them only through selects today, and must not meet NaNs if that ever changes
+        self._ext_bufs = [self.Lext.empty(zero=True), self.Lext.empty(zero=True)]
         self._cur = 0
-        self._tmp = [self.Lext.empty(), self.Lext.empty()]
+        self._tmp = [self.Lext.empty(zero=True), self.Lext.empty(zero=True)]
         self._mask_version = 0
         self._a0_key, self._a0, self.axis0_mode = None, None, None
         self._no_overlap, self._force_exact = False, False
@@ -523,34 +525,48 @@ class SlabStepper:
         self._streams()
         nl, fl, pk = self.nlines, self.flags_int, self.packs_int[0]
         first, last = self.rank == 0, self.rank == self.world - 1
-        plan = None
+        # Every rank evaluates BOTH candidate forms on its own slab and the form is agreed collectively: the eligibility
+        # of 'window' (4 K <= planes of this rank) and the decay tests depend on the rank's slab -- split_planes hands out
+        # slabs that differ by two planes -- and ranks running different forms would exchange messages of different sizes
+        # (a hang or corruption on RCCL).  window: all ranks pass it with the same K; else slab: all ranks pass it;
+        # else exact.
+        def decayed(k):
+            Lw = E.layout(k, self.ny, self.nz, self.Lint.sx)
+            worst = 0.0
+            c = E.vec(6 * nl)
+            if not first:      # first-rows window: (gF, aF) are used, cF must have decayed
+                E.condense(0, v, Lw, Ti[:k], fl[:k], tuple(None if t is None else t[:k] for t in pk), prm.theta,
+                           gam, prm.dt, self.Tinf, c)
+                worst = max(worst, float(c.view(6, nl)[2].abs().max()))
+            if not last:       # last-rows window: (gL, cL) are used, aL must have decayed
+                o = self.nxl - k
+                E.condense(0, v, Lw, Ti[o:], fl[o:], tuple(None if t is None else t[o:] for t in pk), prm.theta,
+                           gam, prm.dt, self.Tinf, c)
+                worst = max(worst, float(c.view(6, nl)[4].abs().max()))
+            return Lw, worst, bool(worst <= self.DECAY_TOL)          # NaN compares false -> not decayed
+        K = self._window_guess(gam)
+        cand = {}
         if not self._force_exact:
-            K = self._window_guess(gam)
             # windows pay off when they are a small part of the slab (pass A on 2K planes instead of all of them)
-            tries = ([('window', K)] if 4 * K <= self.nxl else []) + [('slab', self.nxl)]
-            for mode, k in tries:
-                if mode == 'window' and not self._allow_window:
-                    continue
-                Lw = E.layout(k, self.ny, self.nz, self.Lint.sx)
-                worst = 0.0
-                c = E.vec(6 * nl)
-                if not first:      # first-rows window: (gF, aF) are used, cF must have decayed
-                    E.condense(0, v, Lw, Ti[:k], fl[:k], tuple(None if t is None else t[:k] for t in pk), prm.theta,
-                               gam, prm.dt, self.Tinf, c)
-                    worst = max(worst, float(c.view(6, nl)[2].abs().max()))
-                if not last:       # last-rows window: (gL, cL) are used, aL must have decayed
-                    o = self.nxl - k
-                    E.condense(0, v, Lw, Ti[o:], fl[o:], tuple(None if t is None else t[o:] for t in pk), prm.theta,
-                               gam, prm.dt, self.Tinf, c)
-                    worst = max(worst, float(c.view(6, nl)[4].abs().max()))
-                if worst <= self.DECAY_TOL:          # NaN compares false -> next try / exact
-                    plan = dict(mode=mode, K=k, Lw=Lw, worst=worst)
-                    break
-        flag = E.vec(1); flag.fill_(1.0 if plan is not None else 0.0)
+            if self._allow_window and 4 * K <= self.nxl:
+                cand['window'] = (K,) + decayed(K)
+            cand['slab'] = (self.nxl,) + decayed(self.nxl)
+        prop = E.vec(3)
+        prop[0] = 1.0 if ('window' in cand and cand['window'][3]) else 0.0
+        prop[1] = float(K)
+        prop[2] = 1.0 if ('slab' in cand and cand['slab'][3]) else 0.0
+        allp = E.vec(3 * self.world)
+        self.comm.all_gather(allp, prop)
+        allp = allp.view(self.world, 3)
+        plan = None
+        if float(allp[:, 0].min()) >= 1.0 and float(allp[:, 1].min()) == float(allp[:, 1].max()):
+            k, Lw, worst, _ = cand['window']
+            plan = dict(mode='window', K=k, Lw=Lw, worst=worst)
+        elif float(allp[:, 2].min()) >= 1.0:
+            k, Lw, worst, _ = cand['slab']
+            plan = dict(mode='slab', K=k, Lw=Lw, worst=worst)
+        flag = E.vec(1)
         allf = E.vec(self.world)
-        self.comm.all_gather(allf, flag)
-        if float(allf.min()) < 1.0:
-            plan = None
         if plan is None:
             plan = dict(mode='exact', K=self.nxl)
         plan['fused'] = self._fused_supported(plan['K'])     # the same on every rank (it depends on sizes only...

@@ -46,5 +46,5 @@ def timeit(fn, reps=20):
 
 
 t2 = timeit(two); t1 = timeit(one)
-print('KG=%s n=%d: two kernels %.4f ms, fused %.4f ms (%.0f GB/s on 17 B/cell), identical=%s' % (
-    os.environ.get('ADI_FUSE_KG', 'default'), n, t2, t1, 17.03 * n ** 3 / t1 / 1e6, bool(torch.equal(B, C))), flush=True)
+print('KG=%s n=%d: two kernels %.4f ms, fused %.4f ms (%.0f GB/s on 17 B/cell), identical=%s maxdiff=%.3e' % (
+    os.environ.get('ADI_FUSE_KG', 'default'), n, t2, t1, 17.03 * n ** 3 / t1 / 1e6, bool(torch.equal(B, C)), float((B - C).abs().max())), flush=True)

@@ -141,6 +141,22 @@ def test_neighbour_only_interface_matches_single_domain(world, nx, opts, mode):
     assert rel_linf(got, want) <= 1e-13, rel_linf(got, want)
 
 
+def test_uneven_slabs_agree_on_one_interface_form():
+    """slabs that differ by two planes straddle the window threshold (4 K <= planes, K = 16): rank 0 (64 planes) alone
+    would run 'window', rank 1 (62 planes) 'slab' -- the form is agreed collectively, so both must report the same one
+    and the exchange sizes match (before the agreement this run died with mismatched message sizes)"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import adi_oracle as orc
+    from helpers import run_cart_case, rel_linf
+    name = 'decay:126'
+    c = _case(name)
+    for opts in (dict(prefetch=True), dict(prefetch=True, allow_fused=False, allow_dots=False)):
+        got, modes = _run_world(2, name, [64, 62], c['nsteps'], opts)
+        assert modes == {'slab'}, modes
+        want = run_cart_case(orc, c)['T_final']
+        assert rel_linf(got, want) <= 1e-13, rel_linf(got, want)
+
+
 def test_thin_slabs_fall_back_to_exact():
     """coupling that has not decayed across the middle slab (cfl 200, 4 planes) must select the all-gather solve;
     with two ranks the neighbour-only form is exact whatever the decay (no slab has neighbours on both sides)"""
