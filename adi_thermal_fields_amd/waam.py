@@ -30,40 +30,32 @@ def synthetic_head_mask(nx, ny, nz):
 
 
 def plan_layers(mask_full, n_per_layer):
-    """waam_from_stl_v7_mm.py:436-456: (ks, ke) plane ranges along axis 2, skipping empty planes."""
-    k_indices = np.where(mask_full.any(axis=(0, 1)))[0]
-    if k_indices.size == 0:
+    """Plane ranges (ks, ke) along axis 2, the layer list of waam_from_stl_v7_mm.py:436-456: a layer starts at the next
+    occupied plane, spans at most `n_per_layer` planes and ends on an occupied plane; empty planes belong to no layer.
+    Computed on the sorted indices of the occupied planes (two binary searches per layer) instead of the reference's
+    plane-by-plane scan; the list is the same (tests/test_waam_harness.py pins it against the reference's on gapped masks)."""
+    occ = np.flatnonzero(np.asarray(mask_full).any(axis=(0, 1)))
+    if occ.size == 0:
         raise RuntimeError("empty voxel model")
-    kmin, kmax = int(k_indices.min()), int(k_indices.max())
-    n_per_layer = max(1, int(n_per_layer))
-    layers = []
-    ks = kmin
-    while ks <= kmax:
-        while ks <= kmax and not mask_full[:, :, ks].any():
-            ks += 1
-        if ks > kmax:
-            break
-        ke = min(kmax, ks + n_per_layer - 1)
-        while ke >= ks and not mask_full[:, :, ke].any():
-            ke -= 1
-        if ke < ks:
-            ks += 1
-            continue
-        layers.append((ks, ke))
-        ks = ke + 1
+    n = max(1, int(n_per_layer))
+    layers, p = [], 0
+    while p < occ.size:
+        ks = int(occ[p])
+        q = int(np.searchsorted(occ, ks + n - 1, side='right')) - 1     # last occupied plane inside the span
+        layers.append((ks, int(occ[q])))
+        p = q + 1
     return layers
 
 
 def birth_times(mask_full, layers, dx, bead_width, scan_speed, eta_fill=1.0):
-    """waam_from_stl_v7_mm.py:458-471: cumulative deposition time per layer from its mean cross-section."""
-    times, t = [], 0.0
-    for ks, ke in layers:
-        areas = [float(mask_full[:, :, k].sum()) * dx * dx for k in range(ks, ke + 1)]
-        A = float(np.mean(areas)) if areas else 0.0
-        L = (A / max(bead_width, 1e-12)) * max(eta_fill, 1.0)
-        t += float(L / max(scan_speed, 1e-12))
-        times.append(t)
-    return times
+    """Cumulative deposition time per layer (waam_from_stl_v7_mm.py:458-471): the layer's mean cross-section divided by
+    the bead width gives the track length, the scan speed its duration.  One reduction over the mask for all plane
+    areas; the floating-point operations per layer are the reference's (count*dx*dx, mean, running sum), so the times
+    are bit-identical."""
+    areas = np.asarray(mask_full).sum(axis=(0, 1)).astype(np.float64) * dx * dx
+    bw, v, eta = max(bead_width, 1e-12), max(scan_speed, 1e-12), max(eta_fill, 1.0)
+    dur = [float(np.mean(areas[ks:ke + 1])) / bw * eta / v for ks, ke in layers]
+    return [float(t) for t in np.cumsum(np.asarray(dur, dtype=np.float64))] if dur else []
 
 
 GRAPH_MIN_NSUB = 16      # segments at least this long run through StagedStepper.run (graph capture costs about a step)

@@ -153,6 +153,12 @@ def cyl_case(name):
         c.update(T0=rng.uniform(20.0, 400.0, (7, 1, 9)), robin_r=(0.0, 20.0),  # h == 0 branch
                  zbc=dict(kind_bot='robin', kind_top='robin', h_bot=90.0, h_top=60.0),
                  S=rng.uniform(0.0, 5e8, (7, 1, 9)), dt=0.1, nsteps=3)
+    elif name == 'nphi2_source':  # two phi cells: both neighbours of a cell are the SAME cell (the folded branch of the
+        c.update(geom(6, 2, 9, 7e-4, 9e-4))                # periodic solve; numpy.fft handles n = 2 like any other n)
+        rng = np.random.default_rng(17)
+        c.update(T0=rng.uniform(20.0, 800.0, (6, 2, 9)), robin_r=(300.0, 25.0),
+                 zbc=dict(kind_bot='dirichlet', kind_top='robin', h_top=200.0, T_inf_top=18.0, T_bot=120.0),
+                 S=rng.uniform(0.0, 2e8, (6, 2, 9)), dt=0.15, nsteps=3)
     elif name == 'nphi36_masked':  # non-power-of-two nphi, the shape of tests/test_spiral_vs_analytic.py (6x36x7)
         c.update(geom(6, 36, 7, 5e-4, 1e-3))
         rng = np.random.default_rng(9)
@@ -173,4 +179,4 @@ def cyl_case(name):
 
 _KINDS = ('neumann0', 'dirichlet', 'robin')
 CYL_CASES = (['kat3'] + ['zbc_%s_%s' % (b, t) for b in _KINDS for t in _KINDS]
-             + ['nphi1_source', 'nphi36_masked', 'long_70x12x66'])
+             + ['nphi1_source', 'nphi2_source', 'nphi36_masked', 'long_70x12x66'])

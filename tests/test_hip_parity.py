@@ -46,6 +46,76 @@ def test_cart_vs_golden(hip, name):
         assert np.array_equal(out['T_final'][off], c['T0'][off])
 
 
+@pytest.mark.parametrize('name', ['holes_mixed', 'kat2', 'long_line_70'])
+def test_hand_built_packs_vs_golden(hip, name):
+    """AxisCoeffPack(coeff, dir_mask, dir_val, qflux) built by the caller from host arrays (adi3d_numba_coeff.py:29-36:
+    the constructor copies its arguments) instead of precompute_coeff_packs_unified: read densely by the sweeps
+    (nothing is known about where they are zero), same fields as the reference's packs give"""
+    c = cases.cart_case(name)
+    g = golden('cart', name)
+    nx, ny, nz = c['shape']
+    grid = hip.Grid3D(nx, ny, nz, c['dx'], c['mask'])
+    mat = hip.Material(**c['mat'])
+    prm = hip.Params(c['dt'], c['theta'])
+    srcs = [np.array(g['coeff_' + ax]) for ax in 'xyz']
+    packs = tuple(hip.AxisCoeffPack(srcs[i], g['dir_mask'], g['dir_val'], g['qflux_' + ax]) for i, ax in enumerate('xyz'))
+    assert not any(p.sparse_ok for p in packs)
+    srcs[0][...] = -1.0                                      # the pack holds a copy
+    assert np.array_equal(packs[0].coeff, g['coeff_x'])
+    assert np.array_equal(packs[2].qflux, g['qflux_z']) and np.array_equal(packs[1].dir_mask, g['dir_mask'])
+    p_noq = hip.AxisCoeffPack(g['coeff_x'], g['dir_mask'], g['dir_val'])          # qflux=None -> zeros (:36)
+    assert np.array_equal(p_noq.qflux, np.zeros(c['shape']))
+    T = np.array(c['T0'], dtype=np.float64)
+    for s in range(c['nsteps']):
+        T = hip.adi_step_hip_coeff(T, grid, mat, prm, packs, Tinf=c['Tinf'])
+        if s == 0:
+            assert rel_linf(T, g['T_step1']) <= TOL, rel_linf(T, g['T_step1'])
+    assert rel_linf(T, g['T_final']) <= TOL, rel_linf(T, g['T_final'])
+
+
+def test_float32_state_is_upcast(hip):
+    """waam_from_stl_v7_mm.py:408-413 (--precision float32) hands the step a float32 field: it is up-cast on the way
+    in, the step runs in fp64 and returns a float64 array -- the same bits as stepping the up-cast copy"""
+    c = cases.cart_case('holes_mixed')
+    nx, ny, nz = c['shape']
+    grid = hip.Grid3D(nx, ny, nz, c['dx'], c['mask'])
+    mat = hip.Material(**c['mat'])
+    prm = hip.Params(c['dt'], c['theta'])
+    packs = hip.precompute_coeff_packs_unified(grid, mat, dir_mask=c['dir_mask'], dir_value=c['dir_value'],
+                                               neumann=c['neumann'], robin_h=c['robin_h'])
+    T32 = np.asarray(c['T0'], dtype=np.float32)
+    a = hip.adi_step_hip_coeff(T32, grid, mat, prm, packs, Tinf=c['Tinf'])
+    b = hip.adi_step_hip_coeff(T32.astype(np.float64), grid, mat, prm, packs, Tinf=c['Tinf'])
+    assert a.dtype == np.float64 and np.array_equal(a, b)
+    assert T32.dtype == np.float32                                        # the caller's array is untouched
+
+
+def test_stale_packs_after_mask_rebind_follow_the_reference(hip):
+    """`grid.mask = new` WITHOUT rebuilding the packs: the reference keeps using the old coefficient arrays with the
+    live mask (sweep_axis* read coeff at every in-mask cell, adi3d_numba_coeff.py:150-162).  The device packs are then
+    read densely (their sparsity pattern belongs to the old mask) and the result is the oracle's."""
+    from oracle import adi_oracle as orc
+    c = cases.cart_case('long_line_70')
+    nx, ny, nz = c['shape']
+    rng = np.random.default_rng(5)
+    new_mask = c['mask'].copy()
+    new_mask[rng.random(c['shape']) > 0.97] = False                       # cells that were exposed become interior and
+    new_mask[:, :, nz // 2] = True                                        # vice versa; some holes are filled
+    outs = []
+    for api in (hip, orc):
+        grid = api.Grid3D(nx, ny, nz, c['dx'], c['mask'])
+        mat = api.Material(**c['mat'])
+        prm = api.Params(c['dt'], c['theta'])
+        packs = api.precompute_coeff_packs_unified(grid, mat, neumann=c['neumann'], robin_h=c['robin_h'])
+        grid.mask = new_mask
+        step = getattr(api, 'adi_step_hip_coeff', None) or api.adi_step_numba_coeff
+        T = np.array(c['T0'], dtype=np.float64)
+        for _ in range(2):
+            T = step(T, grid, mat, prm, packs, Tinf=c['Tinf'])
+        outs.append(T)
+    assert rel_linf(outs[0], outs[1]) <= TOL, rel_linf(outs[0], outs[1])
+
+
 @pytest.mark.parametrize('variant,dense', [(0, True), (0, False), (None, False)])
 def test_cart_stages_vs_golden(hip, variant, dense):
     """every stage alone, fed with the reference's own previous stage; variant 0 + dense forces the

@@ -30,6 +30,29 @@ def test_layers_and_times_host_logic():
         waam.plan_layers(np.zeros((3, 3, 3), bool), 2)
 
 
+@pytest.mark.parametrize('seed', range(6))
+def test_layers_and_times_match_the_reference_restatement(seed):
+    """plan_layers / birth_times against the line-by-line restatement of waam_from_stl_v7_mm.py:436-476
+    (oracle/waam_oracle.py) on masks with empty planes inside, at the ends and in runs: identical layer lists,
+    bit-identical times"""
+    from adi_thermal_fields_amd import waam
+    from oracle import waam_oracle as ref
+    rng = np.random.default_rng(seed)
+    nz = int(rng.integers(5, 60))
+    mask = rng.random((6, 7, nz)) < 0.3
+    empty = rng.random(nz) < (0.1 + 0.15 * seed)                 # whole planes switched off
+    mask[:, :, empty] = False
+    if not mask.any():
+        mask[0, 0, nz // 2] = True
+    for n_per in (1, 2, 3, 7):
+        layers = waam.plan_layers(mask, n_per)
+        assert layers == ref.plan_layers(mask, n_per)
+        assert all(isinstance(k, int) for lay in layers for k in lay)
+        t_new = waam.birth_times(mask, layers, 7e-4, bead_width=3e-3, scan_speed=0.013, eta_fill=1.2)
+        t_ref = ref.birth_times(mask, layers, 7e-4, bead_width=3e-3, scan_speed=0.013, eta_fill=1.2)
+        assert t_new == t_ref
+
+
 def test_layer_birth_loop_on_oracle_runs():
     """the loop itself is backend-agnostic: run it on the CPU oracle (tiny grid)"""
     from oracle import adi_oracle as orc
@@ -174,6 +197,40 @@ def test_config5_full_256x256x320_4_slabs_match_one_domain():
     assert np.all(want[~mask] == 20.0) and 20.0 < want[mask].max() <= 1000.0 + 1e-9 and want.min() >= 20.0 - 1e-9
     got = _slab_run(4, [64, 64, 64, 64], mask, dx, layers, times, outs, theta)
     assert rel_linf(got, want) <= 1e-11, rel_linf(got, want)
+
+
+@pytest.mark.gpu
+def test_config5_full_size_theta_half_as_specified_before_divergence():
+    """BASELINE.json configs[4] exactly as SURVEY.md 8(d) writes it -- 256 x 256 x 320 synthetic head, layers of 2 planes,
+    cfl 2000, theta = 0.5, Robin h = 40, Ts = 1000 -- over the window in which the reference scheme is still bounded.
+    At theta = 0.5 / cfl = 2000 the factored scheme itself is unstable on this mask (reference defect D9, DESIGN.md
+    section 6: in the pinned oracle the field stays inside [20, 1000] through step 20, reaches +-1.3e5 at step 23 and
+    +-7.2e7 at step 26), so the full-size comparison with the CPU oracle covers the first 21 births = 20 steps:
+    HIP == OpenMP oracle to 1e-10."""
+    from oracle import adi_oracle as orc
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from adi_thermal_fields_amd import waam
+    shape = (256, 256, 320)
+    mask = waam.synthetic_head_mask(*shape)
+    layers = waam.plan_layers(mask, 2)
+    dx = 1e-3
+    times = waam.birth_times(mask, layers, dx, bead_width=4e-3, scan_speed=0.02)
+    nb = 21
+    outs = [times[nb - 1]]
+
+    class OmpOracle:                      # the oracle module with its OpenMP step (same arithmetic, bit-identical)
+        Grid3D, Material, Params = orc.Grid3D, orc.Material, orc.Params
+        precompute_coeff_packs_unified = staticmethod(orc.precompute_coeff_packs_unified)
+
+        @staticmethod
+        def adi_step_numba_coeff(T, grid, mat, params, packs, Tinf=0.0):
+            return orc.adi_run(T, grid, mat, params, packs, Tinf=Tinf, nsteps=1, omp=True)
+    want, n1 = waam.run_layer_birth(OmpOracle, mask, dx, STEEL, 40.0, 20.0, 1000.0, 0.5, 2000.0, layers[:nb], times[:nb], outs)
+    got, n2 = waam.run_layer_birth(hip, mask, dx, STEEL, 40.0, 20.0, 1000.0, 0.5, 2000.0, layers[:nb], times[:nb], outs)
+    assert n1 == n2 == 20, (n1, n2)
+    assert want.max() <= 1000.0 + 1e-6 and want.min() >= 20.0 - 1e-6      # still inside the bounded window
+    assert rel_linf(got, want) <= 1e-10, rel_linf(got, want)
+    assert np.array_equal(got[~mask], want[~mask])
 
 
 @pytest.mark.gpu
