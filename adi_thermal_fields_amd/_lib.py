@@ -88,6 +88,7 @@ SIGNATURES = {
     'adi_cyl_plan_destroy': (c_int, [c_void_p]),
     'adi_cyl_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_double, c_double, c_void_p]),
+    'adi_cyl_sweep': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_void_p]),
     'adi_ctx_create': (c_int, [c_int, c_int, c_int, c_double, c_int, c_void_pp]),
     'adi_ctx_destroy': (c_int, [c_void_p]),
     'adi_ctx_set_mask': (c_int, [c_void_p, c_void_p]),

@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import lib, check
 from .adi3d_hip_coeff import DeviceField, Layout, to_device, _device, _stream, _p, _wrap
 
-__all__ = ['GridCyl', 'Material', 'Params', 'RobinR', 'ZBC', 'adi_step', 'adi_step_masked', 'DeviceField', 'to_device']
+__all__ = ['StagedCylStepper', 'GridCyl', 'Material', 'Params', 'RobinR', 'ZBC', 'adi_step', 'adi_step_masked', 'DeviceField', 'to_device']
 
 
 class GridCyl:  # adi3d_cyl_phi_v3.py:33-43
@@ -128,6 +128,34 @@ def _run(Tn, grid, mat, prm, robin_r, zbc, S, active, T_void, T_inner):
     check(lib.adi_cyl_step(pl.handle, _p(t), _p(out), _p(ta), _p(tb), _p(d_S), _p(d_act),
                            float(T_void), float(T_inner), _stream()))
     return _wrap(out, kind)
+
+
+class StagedCylStepper:
+    """adi_step (BE) with its arguments resolved once, for loops over a device-resident field and per-sweep timing:
+    `events`: optional list of 4 torch.cuda.Event recorded on the launch stream before / between / after the r, phi
+    and z sweeps (adi_cyl_sweep of the C ABI)."""
+    stage_names = ['sweep_r', 'sweep_phi', 'sweep_z_contig']
+    stage_bytes_per_cell = [16.0, 16.0, 16.0]          # SURVEY.md 8(d): field in + field out per sweep
+
+    def __init__(self, grid, mat, prm, robin_r, zbc):
+        if prm.scheme == "douglas":
+            raise NotImplementedError("scheme='douglas' has no valid oracle (see adi_step)")
+        self.grid = grid
+        self.plan = _plan(grid, mat, prm.dt, robin_r, zbc)
+
+    def step(self, T, events=None):
+        g = self.grid
+        t = g.layout.to_layout(T, torch.float64)
+        ta, tb = g.scratch()
+        out = g.layout.empty()
+        seq = ((0, t, ta), (1, ta, tb), (2, tb, out)) if g.nphi > 1 else ((0, t, ta), (2, ta, out))
+        if events is not None:
+            events[0].record()
+        for ax, a, b in seq:
+            check(lib.adi_cyl_sweep(self.plan.handle, ax, _p(a), _p(b), None, None, 0.0, 0.0, _stream()))
+            if events is not None:
+                events[ax + 1].record()
+        return DeviceField(out)
 
 
 def adi_step(Tn, grid, mat, prm, robin_r, zbc, S=None, theta=None):

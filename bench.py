@@ -36,6 +36,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--n', type=int, default=512, help='cells per axis per GPU')
+    ap.add_argument('--config', choices=['cart', 'cyl'], default='cart',
+                    help="cart: the headline 512^3 Cartesian workload (default); cyl: BASELINE.json configs[3], the "
+                         "cylindrical 128 x 256 x 512 BE step on one GPU (replicas only at N > 1: it does not shard)")
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-n', type=int, default=256, help='edge of the bounded CPU-baseline sample')
     ap.add_argument('--force-dist', action='store_true',
@@ -96,9 +99,123 @@ def emit(text):
         os.write(_STDOUT_FD, (text + '\n').encode())
 
 
+def main_cyl(a):
+    """BASELINE.json configs[3] / SURVEY.md 8(d) config 4: cylindrical (r, phi, z) = 128 x 256 x 512, dr = dz = 2.5e-4,
+    BE, dt = 0.05, RobinR(400, 20), z: neumann0 / robin h = 500, T0 = 20 with the top 16 z-planes at 1000.
+    One step = r sweep + phi sweep + z sweep on a field resident in HBM; 16 B/cell/sweep (field in + field out:
+    the coefficients are per-index constants).  N > 1: independent replicas (the path does not shard)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == a.gpus, 'WORLD_SIZE (%d) != --gpus (%d)' % (world, a.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+    import adi_thermal_fields_amd.adi3d_hip_cyl as cyl
+    nr, nphi, nz = 128, 256, 512
+    g = cyl.GridCyl(nr, nphi, nz, 2.5e-4, 2 * np.pi / nphi, 2.5e-4, 0.032)
+    mat = cyl.Material(7800.0, 490.0, 54.0)
+    prm = cyl.Params(0.05, 1.0, "be")
+    rr = cyl.RobinR(400.0, 20.0)
+    zbc = cyl.ZBC('neumann0', 'robin', h_top=500.0, T_inf_top=20.0)
+    T0 = np.full((nr, nphi, nz), 20.0); T0[:, :, -16:] = 1000.0
+    T = cyl.to_device(T0)
+    st = cyl.StagedCylStepper(g, mat, prm, rr, zbc)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        T = st.step(T)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(a.steps)]
+    sync()
+    t0 = time.perf_counter()
+    for s_ in range(a.steps):
+        T = st.step(T, events=ev[s_])
+    sync()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = elapsed.item()
+    assert bool(torch.isfinite(T.t).all().item())
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+    N = nr * nphi * nz
+    ms = np.array([[ev[s_][i].elapsed_time(ev[s_][i + 1]) for i in range(3)] for s_ in range(a.steps)]).mean(axis=0)
+    kernels = {}
+    for i, nm in enumerate(st.stage_names):
+        gbs = st.stage_bytes_per_cell[i] * N / (ms[i] * 1e-3) / 1e9
+        kernels[nm] = dict(ms=round(float(ms[i]), 4), bytes_per_cell=st.stage_bytes_per_cell[i],
+                           achieved_gbs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+    dom = max(kernels, key=lambda k: kernels[k]['ms'])
+    ms_per_step = elapsed / a.steps * 1e3
+    line = dict(metric='adi_cyl_steps_per_sec_128x256x512_fp64', value=round(world * a.steps / elapsed, 3),
+                unit='steps/s (128x256x512 cylindrical BE steps, all GPUs)', n_gpus=world, steps=a.steps, warmup=a.warmup,
+                ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
+                data='synthetic',
+                config=dict(workload='cylindrical (r,phi,z) 128x256x512 fp64, BE dt=0.05, RobinR(400,20), z: neumann0 / '
+                                     'robin h=500, T0=20 with the top 16 z-planes at 1000 (BASELINE.json configs[3])',
+                            cells_per_gpu=N, decomposition='replicas only' if world > 1 else 'none'),
+                cell_updates_per_s=round(world * N * a.steps / elapsed, 1),
+                step_achieved_gbs=round(48.0 * N / (ms_per_step * 1e-3) / 1e9, 1),
+                roofline=dict(bound='hbm', kernel=dom, achieved=kernels[dom]['achieved_gbs'], peak=HBM_PEAK_GBS,
+                              unit='GB/s', frac=kernels[dom]['frac'], traffic=measured_traffic(dom, 'cyl')),
+                kernels=kernels)
+    if not a.no_cpu:
+        # the NumPy restatement of adi3d_cyl_phi_v3.adi_step (BE) on a bounded sample of the same workload
+        from oracle import cyl_oracle as orc
+        cn = (128, 256, 512)      # the full workload: one NumPy step takes 15-20 s
+        og = orc.GridCyl(cn[0], cn[1], cn[2], 2.5e-4, 2 * np.pi / cn[1], 2.5e-4, cn[0] * 2.5e-4)
+        om = orc.Material(7800.0, 490.0, 54.0); op = orc.Params(0.05, 1.0, "be")
+        Tc = np.full(cn, 20.0); Tc[:, :, -16:] = 1000.0
+        orr = orc.RobinR(400.0, 20.0); oz = orc.ZBC('neumann0', 'robin', h_top=500.0, T_inf_top=20.0)
+        t0 = time.perf_counter(); ksteps = 1
+        for _ in range(ksteps):
+            Tc = orc.adi_step(Tc, og, om, op, orr, oz)
+        dtc = time.perf_counter() - t0
+        line['cpu_baseline'] = dict(value=ksteps * float(np.prod(cn)) / N / dtc, unit='steps/s (128x256x512-cell equivalent)',
+                                    cores=1, kind='port',
+                                    sample='%dx%dx%d cells x %d steps of the same BE workload, %.1f s, oracle/cyl_oracle.py '
+                                           '(NumPy, as the reference is)' % (cn + (ksteps, dtc)))
+    emit(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def so_stamp():
+    """identity of the built library the numbers come from (first 16 hex digits of its SHA-256)"""
+    import hashlib
+    p = os.path.join(ROOT, 'adi_thermal_fields_amd', 'csrc', 'libadi_hip.so')
+    h = hashlib.sha256()
+    with open(p, 'rb') as f:
+        for blk in iter(lambda: f.read(1 << 20), b''):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel, config='cart'):
+    """HBM bytes per launch of `kernel` from the PMC passes kept in profiles/pmc_traffic.json -- only when that file was
+    produced with THIS build of the library (it carries the library's hash); otherwise null"""
+    tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        d = json.load(open(tp))
+        if d.get('library_sha256_16') != so_stamp():
+            return None
+        return (d.get(config) or {}).get(kernel)
+    except Exception:
+        return None
+
+
 def main():
     claim_stdout()
     a = parse()
+    if a.config == 'cyl':
+        return main_cyl(a)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     rehearse = a.rehearse_world if (a.rehearse_world > 1 and world == 1 and a.gpus == 1) else 0
@@ -219,13 +336,7 @@ def main():
                           frac=round(42 * N / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
 
     dom = max(kernels, key=lambda k: kernels[k]['ms'])
-    traffic = None
-    tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(tp):
-        try:
-            traffic = json.load(open(tp)).get(dom)
-        except Exception:
-            traffic = None
+    traffic = measured_traffic(dom, 'cart')
     ms_per_step = elapsed / a.steps * 1e3
     value = world * N / 512 ** 3 * a.steps / elapsed
     line = dict(
