@@ -44,6 +44,10 @@ SIGNATURES = {
                                  c_int_p, c_double_p, c_void_pp, c_int_p, c_double_p, c_void_pp,
                                  c_void_pp, c_void_pp, c_void_p]),
     'adi_build_nbr_flags': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p]),
+    'adi_build_nbr_flags_planes': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_int, c_int, c_void_p]),
+    'adi_build_coeffs_planes': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_double, c_double, c_double,
+                                        c_int_p, c_double_p, c_void_pp, c_int_p, c_double_p, c_void_pp,
+                                        c_void_pp, c_void_pp, c_int, c_int, c_void_p]),
     'adi_explicit_rhs': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_double, c_double, c_double,
                                  c_double, c_void_p, c_void_p]),
     'adi_explicit_rhs_planes': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_double, c_double, c_double,
@@ -80,6 +84,9 @@ SIGNATURES = {
     'adi_morph6': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'adi_flood_outside': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int_p, c_void_p]),
     'adi_pack_frame_f32be': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p]),
+    'adi_count_exposed_faces': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p, c_void_p]),
+    'adi_birth_planes': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_int, c_double, c_void_p,
+                                 c_void_p]),
     'adi_masked_fill': (c_int, [c_void_p, c_void_p, c_size_t, c_double, c_void_p]),
     'adi_mask_or': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'adi_cyl_plan_create': (c_int, [c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double, c_double, c_double,

@@ -36,7 +36,8 @@ from ._lib import lib, check, ptr_array, FACES
 
 __all__ = ['Grid3D', 'Material', 'Params', 'AxisCoeffPack', 'exposed_mask', 'precompute_coeff_packs_unified',
            'adi_step_hip_coeff', 'adi_step_numba_coeff', 'adi_step_gpu_coeff', 'DeviceField', 'to_device',
-           'adi_explicit_rhs', 'adi_sweep_axis', 'StagedStepper', 'Layout', 'apply_surface_impulse_Q']
+           'adi_explicit_rhs', 'adi_sweep_axis', 'StagedStepper', 'Layout', 'apply_surface_impulse_Q',
+           'exposed_faces_per_layer', 'count_exposed_faces', 'perimeter_ratio', 'birth_planes', 'BirthPacks']
 
 
 def _device():
@@ -193,6 +194,7 @@ class Grid3D:
         self._mask = None
         self._d_mask = None
         self._d_flags = None
+        self._all_solid = None
         self._scratch = None
         self.mask_version = 0
         self.mask = np.asarray(mask).astype(np.bool_, copy=True, order='C')
@@ -220,19 +222,39 @@ class Grid3D:
         self._mask = m                                   # rebinding keeps the caller's object, as in the reference
         self.sync_mask()
 
-    def set_mask_device(self, d_mask):
+    def _rebuild_flags(self, k_begin=0, k_end=None):
+        """neighbour flags of the device mask, in place (the buffer is zero-filled once: plane padding)"""
+        if self._d_flags is None:
+            self._d_flags = self.layout.empty(torch.uint8, zero=True)
+        k_end = self.nz if k_end is None else k_end
+        check(lib.adi_build_nbr_flags_planes(_p(self._d_mask), self.nx, self.ny, self.nz, self.sx, _p(self._d_flags),
+                                             int(k_begin), int(k_end), _stream()))
+        self.mask_version += 1
+        self._all_solid = None
+
+    @property
+    def all_solid(self):
+        """hint for the kernels (no surface inside the box); evaluated on demand -- it costs a host synchronisation"""
+        if self._all_solid is None:
+            self._all_solid = bool((self._d_mask != 0).all().item()) if self._d_mask is not None else False
+        return self._all_solid
+
+    @all_solid.setter
+    def all_solid(self, v):
+        self._all_solid = None if v is None else bool(v)
+
+    def set_mask_device(self, d_mask, k_begin=0, k_end=None, all_solid=None):
         """`grid.mask = ...` for a mask that already lives on the device (uint8 tensor in the grid's layout, e.g.
-        updated in place by a birth): no host round trip; the neighbour flags are rebuilt from it and the host copy is
-        downloaded only if somebody reads `grid.mask`.  The device loop of waam.run_layer_birth uses this."""
+        updated in place by a birth): no host round trip; the neighbour flags are rebuilt from it (only the planes
+        [k_begin, k_end) of axis 2 when the caller knows nothing else changed) and the host copy is downloaded only if
+        somebody reads `grid.mask`.  `all_solid`: the caller's knowledge of the box hint (None: evaluated on demand).
+        The device loop of waam.run_layer_birth uses this."""
         assert self.layout.is_native(d_mask) and d_mask.dtype == torch.uint8
         self._d_mask = d_mask
         self._mask = None
         self._device_mask = True
-        self._d_flags = self.layout.empty(torch.uint8, zero=True)
-        check(lib.adi_build_nbr_flags(_p(self._d_mask), self.nx, self.ny, self.nz, self.sx, _p(self._d_flags),
-                                      _stream()))
-        self.mask_version += 1
-        self.all_solid = bool((d_mask != 0).all())
+        self._rebuild_flags(k_begin, k_end)
+        self._all_solid = all_solid
         return self._d_mask
 
     def sync_mask(self):
@@ -242,11 +264,8 @@ class Grid3D:
             return self._d_mask
         self._device_mask = False
         self._d_mask = self.layout.to_layout(self._mask, torch.uint8)
-        self._d_flags = self.layout.empty(torch.uint8, zero=True)
-        check(lib.adi_build_nbr_flags(_p(self._d_mask), self.nx, self.ny, self.nz, self.sx, _p(self._d_flags),
-                                      _stream()))
-        self.mask_version += 1
-        self.all_solid = bool(np.asarray(self._mask).all())     # hint for the kernels: no surface inside the box
+        self._rebuild_flags()
+        self._all_solid = bool(np.asarray(self._mask).all())     # hint for the kernels: no surface inside the box
         return self._d_mask
 
     @property
@@ -304,8 +323,32 @@ class AxisCoeffPack:
         # Set by precompute_coeff_packs_unified only: coeff/qflux are non-zero just on cells exposed along the
         # pack's axis, so the sweep may skip loading them elsewhere.  Hand-built packs are read densely.
         self.sparse_ok = False
-        self.exposed_fraction = 1.0    # fraction of cells exposed along the axis (for the byte accounting)
-        self.dir_fraction = 1.0
+        self._fractions = None         # (grid, axis, mask version) the byte accounting is evaluated from, on demand
+        self._exposed_fraction = 1.0   # fraction of cells exposed along the axis
+        self._dir_fraction = 1.0
+
+    def _eval_fractions(self):
+        if self._fractions is not None:
+            grid, a, ver = self._fractions
+            self._fractions = None
+            if grid.mask_version != ver:       # the mask moved on before anybody asked: keep the dense figures
+                return
+            fl = grid.d_flags
+            L = self.layout
+            ncell = float(L.nx * L.ny * L.nz)
+            inmask = (fl & 1) == 1
+            self._exposed_fraction = float((inmask & (((fl >> (1 + 2 * a)) & 3) != 3)).sum().item()) / ncell
+            self._dir_fraction = float(self.d_dir_mask.sum().item()) / ncell if self.has_dir else 0.0
+
+    @property
+    def exposed_fraction(self):
+        self._eval_fractions()
+        return self._exposed_fraction
+
+    @property
+    def dir_fraction(self):
+        self._eval_fractions()
+        return self._dir_fraction
 
     @property
     def variant(self):
@@ -410,15 +453,10 @@ def precompute_coeff_packs_unified(grid, mat, dir_mask=None, dir_value=None, neu
             d_dv = L.to_layout(dir_value, torch.float64)
     packs = tuple(AxisCoeffPack(coeff[a], d_dm, d_dv, qflux[a], _has_dir=has_dir, _has_q=has_q, _layout=L)
                   for a in range(3))
-    fl = grid.d_flags
-    inmask = (fl & 1) == 1
-    ncell = float(grid.nx * grid.ny * grid.nz)
-    dfrac = float(d_dm.sum().item()) / ncell if has_dir else 0.0
     for a, p in enumerate(packs):
         p.mask_version = grid.mask_version
         p.sparse_ok = True
-        p.exposed_fraction = float((inmask & (((fl >> (1 + 2 * a)) & 3) != 3)).sum().item()) / ncell
-        p.dir_fraction = dfrac
+        p._fractions = (grid, a, grid.mask_version)      # exposed / Dirichlet fractions: evaluated when somebody asks
     return packs
 
 
@@ -570,6 +608,103 @@ def apply_surface_impulse_Q(T, grid, mat, Q, face='z-'):
     else:
         sel = np.asarray(grid.mask)[sl]
         T[sl][sel] += dT
+
+
+# ---- per-voxel Robin correction: perimeter ratio --------------------------------------------
+_LATERAL = ('x-', 'x+', 'y-', 'y+')
+
+
+def exposed_faces_per_layer(mask_or_grid, faces=_LATERAL):
+    """Number of exposed faces (in-mask cell whose neighbour across the face is outside the mask or the box) per plane
+    k of axis 2, counted on the device from the neighbour-flags digest: int64 array of length nz.  With the four
+    lateral faces this is the digital perimeter of every layer divided by dx."""
+    for f in faces:
+        if f not in FACES:
+            raise ValueError("bad face")
+    if isinstance(mask_or_grid, Grid3D):
+        g = mask_or_grid
+    else:
+        m = np.asarray(mask_or_grid)
+        g = Grid3D(m.shape[0], m.shape[1], m.shape[2], 1.0, m)
+    bits = sum(1 << FACES.index(f) for f in set(faces))
+    counts = torch.empty(g.nz, dtype=torch.int64, device=_device())
+    check(lib.adi_count_exposed_faces(_p(g.d_flags), g.nx, g.ny, g.nz, g.sx, bits, _p(counts), _stream()))
+    return counts.cpu().numpy()
+
+
+def count_exposed_faces(mask2d):
+    """quick_compare_layer_birth_robin_v3.py:97-108: exposed x-/x+/y-/y+ faces of a 2-D section (an integer)."""
+    m = np.asarray(mask2d).astype(bool)
+    assert m.ndim == 2
+    return int(exposed_faces_per_layer(m[:, :, None])[0])
+
+
+def perimeter_ratio(mask2d, dx, perim_true):
+    """gamma = true perimeter / digital perimeter of the voxelised section (quick_compare_layer_birth_robin_v3.py:109-112);
+    the lateral Robin coefficient of a staircase surface is scaled by it: h_side_eff = h_side * gamma (pi/4 for a
+    large disk)."""
+    faces = count_exposed_faces(mask2d)
+    if faces == 0:
+        raise ValueError("empty section")
+    return float(perim_true) / (faces * float(dx))
+
+
+# ---- layer birth on the device (SURVEY.md 8(f) rank 1) --------------------------------------------------------------
+def birth_planes(T, d_active, d_full, grid, k_begin, k_end, Ts, count=None):
+    """activate_layer (waam_from_stl_v7_mm.py:487-495) on the planes [k_begin, k_end) of axis 2, one kernel:
+    newborn = full & ~active; T[newborn] = Ts; active |= full.  T: DeviceField; d_active / d_full: uint8 tensors in the
+    grid's layout.  `count`: optional int64 device tensor (1 element) that receives the number of newborn cells."""
+    L = grid.layout
+    assert L.is_native(d_active) and L.is_native(d_full) and L.is_native(T.t)
+    if count is None:
+        count = torch.empty(1, dtype=torch.int64, device=T.t.device)
+    check(lib.adi_birth_planes(_p(T.t), _p(d_active), _p(d_full), grid.nx, grid.ny, grid.nz, grid.sx, int(k_begin),
+                               int(k_end), float(Ts), _p(count), _stream()))
+    return count
+
+
+class BirthPacks:
+    """The coefficient packs of a part that grows by layer births along axis 2 (precompute_coeff_packs_unified with
+    scalar / None face specifications, no Dirichlet cells), kept in HBM and UPDATED IN PLACE after a birth: only the
+    planes of the new layer and the one below / above it change exposure, so the flags and the six coefficient arrays
+    are rebuilt on [k_begin - 1, k_end + 1) instead of the whole box -- the same arrays the reference's full rebuild
+    (waam_from_stl_v7_mm.py:534) would give."""
+
+    def __init__(self, grid, mat, robin_h=None, neumann=None):
+        self.grid, self.mat = grid, mat
+        L = grid.layout
+
+        def spec(v):
+            if v is None:
+                return (_lib.FACE_NONE, 0.0)
+            if not np.isscalar(v):
+                raise TypeError("BirthPacks takes scalar face specifications (use precompute_coeff_packs_unified for fields)")
+            return (_lib.FACE_SCALAR, float(v))
+        hs = [spec(None if robin_h is None else (robin_h.get(f, 0.0) if isinstance(robin_h, dict) else robin_h)) for f in FACES]
+        qs = [spec(neumann.get(f) if neumann is not None else None) for f in FACES]
+        self._args = ((ctypes.c_int * 6)(*[h[0] for h in hs]), (ctypes.c_double * 6)(*[h[1] for h in hs]), ptr_array([None] * 6),
+                      (ctypes.c_int * 6)(*[q[0] for q in qs]), (ctypes.c_double * 6)(*[q[1] for q in qs]), ptr_array([None] * 6))
+        self.coeff = [L.empty(zero=True) for _ in range(3)]
+        self.qflux = [L.empty(zero=True) for _ in range(3)]
+        has_q = any(q[0] != _lib.FACE_NONE for q in qs)
+        self.packs = tuple(AxisCoeffPack(self.coeff[a], None, None, self.qflux[a], _has_dir=False, _has_q=has_q, _layout=L)
+                           for a in range(3))
+        for p in self.packs:
+            p.sparse_ok = True
+        self.update(0, grid.nz)
+
+    def update(self, k_begin, k_end):
+        """rebuild the planes [k_begin, k_end) of axis 2 from the grid's current device mask"""
+        g, m = self.grid, self.mat
+        k0, k1 = max(0, int(k_begin)), min(g.nz, int(k_end))
+        hm, hs, hf, qm, qs, qf = self._args
+        check(lib.adi_build_coeffs_planes(_p(g.d_mask), g.nx, g.ny, g.nz, g.sx, g.dx, m.rho, m.cp, hm, hs, hf, qm, qs, qf,
+                                          ptr_array([c.data_ptr() for c in self.coeff]),
+                                          ptr_array([q.data_ptr() for q in self.qflux]), k0, k1, _stream()))
+        for a, p in enumerate(self.packs):
+            p.mask_version = g.mask_version
+            p._fractions = (g, a, g.mask_version)
+        return self.packs
 
 
 # the reference's backend-specific names, so its drivers run unchanged on this module

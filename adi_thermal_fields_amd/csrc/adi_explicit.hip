@@ -246,6 +246,19 @@ __device__ __forceinline__ bool cell_of(long q, const Lay &L, int &i, int &j, in
     return true;
 }
 
+// the same restricted to the planes [k0, k1) of axis 2 (the planes a layer birth touches)
+__device__ __forceinline__ bool cell_of_k(long q, const Lay &L, int k0, int k1, int &i, int &j, int &k, long &p)
+{
+    const int nk = k1 - k0;
+    if (q >= (long)L.nx * L.ny * nk) return false;
+    const long row = q / nk;
+    k = k0 + (int)(q - row * nk);
+    i = (int)(row / L.ny);
+    j = (int)(row - (long)i * L.ny);
+    p = (long)i * L.sx + (long)j * L.nz + k;
+    return true;
+}
+
 // generic form (odd nz or unaligned views): one cell per thread
 __global__ __launch_bounds__(256) void k_explicit_cell(const double *__restrict__ T, const uint8_t *__restrict__ flags,
                                                   double *__restrict__ R0, Lay L, double invdx2, double f, int i_begin,
@@ -272,11 +285,12 @@ __global__ __launch_bounds__(256) void k_explicit_cell(const double *__restrict_
 // neighbour flags: bit0 = cell in mask, bit(1 + 2*axis) / bit(2 + 2*axis) = the minus / plus neighbour along
 // `axis` exists and is in the mask.  Derived from the mask whenever it changes (the mask "folds into the
 // coefficient build on device"); halo planes of a slab decomposition are simply part of the mask array.
-__global__ __launch_bounds__(256) void k_build_flags(const uint8_t *__restrict__ mask, Lay L, uint8_t *__restrict__ flags)
+__global__ __launch_bounds__(256) void k_build_flags(const uint8_t *__restrict__ mask, Lay L, int k0, int k1,
+                                                     uint8_t *__restrict__ flags)
 {
     int i, j, k;
     long p;
-    if (!cell_of((long)blockIdx.x * blockDim.x + threadIdx.x, L, i, j, k, p)) return;
+    if (!cell_of_k((long)blockIdx.x * blockDim.x + threadIdx.x, L, k0, k1, i, j, k, p)) return;
     const long sx = L.sx, sy = L.nz;
     unsigned f = 0;
     if (mask[p]) {
@@ -301,8 +315,8 @@ struct FaceSpec {
     const double *field[6];
 };
 
-__global__ __launch_bounds__(256) void k_build_coeffs(const uint8_t *__restrict__ mask, Lay L, double A, double Ccell,
-                                                      FaceSpec h, FaceSpec q, double *__restrict__ c0,
+__global__ __launch_bounds__(256) void k_build_coeffs(const uint8_t *__restrict__ mask, Lay L, int k0, int k1, double A,
+                                                      double Ccell, FaceSpec h, FaceSpec q, double *__restrict__ c0,
                                                       double *__restrict__ c1, double *__restrict__ c2,
                                                       double *__restrict__ q0, double *__restrict__ q1,
                                                       double *__restrict__ q2)
@@ -310,7 +324,7 @@ __global__ __launch_bounds__(256) void k_build_coeffs(const uint8_t *__restrict_
 #pragma clang fp contract(off)
     int i, j, k;
     long p;
-    if (!cell_of((long)blockIdx.x * blockDim.x + threadIdx.x, L, i, j, k, p)) return;
+    if (!cell_of_k((long)blockIdx.x * blockDim.x + threadIdx.x, L, k0, k1, i, j, k, p)) return;
     const long st[3] = {L.sx, (long)L.nz, 1};
     const int pos[3] = {i, j, k}, nn[3] = {L.nx, L.ny, L.nz};
     const bool m = mask[p] != 0;
@@ -352,6 +366,49 @@ __global__ __launch_bounds__(256) void k_exposed(const uint8_t *__restrict__ mas
     out[p] = e ? 1 : 0;
 }
 
+// Exposed lateral faces per plane k of axis 2, from the neighbour-flags digest: an in-mask cell exposes one face for every
+// neighbour bit in `bits` that is clear (bits 1..6 = x-, x+, y-, y+, z-, z+; the domain boundary counts as exposed, as in
+// exposed_mask).  This is the count loop of quick_compare_layer_birth_robin_v3.py:97-108 for every layer at once.
+// Thread t of a block owns plane k = blockIdx.x*256 + t and walks a chunk of (i, j) rows: coalesced along k, one
+// 64-bit atomic per thread at the end.
+__global__ __launch_bounds__(256) void k_count_exposed(const uint8_t *__restrict__ flags, Lay L, unsigned bits, int rows_per_block,
+                                                       unsigned long long *__restrict__ counts)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= L.nz) return;
+    const long nrows = (long)L.nx * L.ny;
+    const long r0 = (long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < nrows ? r0 + rows_per_block : nrows;
+    unsigned long long c = 0;
+    for (long r = r0; r < r1; ++r) {
+        const unsigned i = (unsigned)r / (unsigned)L.ny, j = (unsigned)r - i * (unsigned)L.ny;
+        const unsigned f = flags[(long)i * L.sx + (long)j * L.nz + k];
+        if (f & 1u) c += __popc(~f & bits & 0x7eu);
+    }
+    if (c) atomicAdd(&counts[k], c);
+}
+
+// A birth in one pass (activate_layer, waam_from_stl_v7_mm.py:487-495): on the planes [k0, k1) of axis 2
+//     newborn = full & ~active;   T[newborn] = Ts;   active |= full          and the number of newborn cells is counted.
+// Cell q of the (nx*ny) x (k1-k0) box: consecutive threads run along k.
+__global__ __launch_bounds__(256) void k_birth(double *__restrict__ T, uint8_t *__restrict__ active,
+                                               const uint8_t *__restrict__ full, Lay L, int k0, int k1, double Ts,
+                                               unsigned long long *__restrict__ n_new)
+{
+    const int nk = k1 - k0;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)L.nx * L.ny * nk;
+    unsigned born = 0;
+    if (q < total) {
+        const long row = q / nk;
+        const int k = k0 + (int)(q - row * nk);
+        const unsigned i = (unsigned)row / (unsigned)L.ny, j = (unsigned)row - i * (unsigned)L.ny;
+        const long p = (long)i * L.sx + (long)j * L.nz + k;
+        if (full[p] != 0 && active[p] == 0) { T[p] = Ts; active[p] = 1; born = 1; }
+    }
+    const unsigned long long b = __ballot(born);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_new, (unsigned long long)__popcll(b));
+}
+
 __global__ __launch_bounds__(256) void k_masked_fill(double *__restrict__ T, const uint8_t *__restrict__ sel,
                                                      size_t n, double v)
 {
@@ -385,14 +442,52 @@ int adi_exposed_mask(const uint8_t *d_mask, int nx, int ny, int nz, long plane_s
     return ADI_OK;
 }
 
-int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, double dx, double rho,
-                     double cp, const int *h_mode, const double *h_scalar, const double *const *d_h_field,
-                     const int *q_mode, const double *q_scalar, const double *const *d_q_field,
-                     double *const *d_coeff, double *const *d_qflux, void *stream)
+int adi_count_exposed_faces(const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride, int face_bits,
+                            unsigned long long *d_counts, void *stream)
+{
+    ADI_REQUIRE(d_flags && d_counts, "adi_count_exposed_faces: null argument");
+    ADI_REQUIRE(face_bits > 0 && face_bits < 64, "adi_count_exposed_faces: face_bits selects none of the six faces");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    hipStream_t st = as_stream(stream);
+    ADI_HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nz * sizeof(unsigned long long), st));
+    const long nrows = (long)nx * ny;
+    const int rows_per_block = nrows > 4096 ? 256 : 16;
+    const dim3 grid((unsigned)((nz + 255) / 256), (unsigned)((nrows + rows_per_block - 1) / rows_per_block));
+    hipLaunchKernelGGL(k_count_exposed, grid, dim3(256), 0, st, d_flags, L, (unsigned)face_bits << 1, rows_per_block, d_counts);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+int adi_birth_planes(double *d_T, uint8_t *d_active, const uint8_t *d_full, int nx, int ny, int nz, long plane_stride,
+                     int k_begin, int k_end, double Ts, unsigned long long *d_newborn, void *stream)
+{
+    ADI_REQUIRE(d_T && d_active && d_full && d_newborn, "adi_birth_planes: null argument");
+    ADI_REQUIRE(d_active != d_full, "adi_birth_planes: the active mask aliases the full mask");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    ADI_REQUIRE(k_begin >= 0 && k_end <= nz && k_begin <= k_end, "adi_birth_planes: bad plane range [%d, %d)", k_begin, k_end);
+    hipStream_t st = as_stream(stream);
+    ADI_HIP_TRY(hipMemsetAsync(d_newborn, 0, sizeof(unsigned long long), st));
+    if (k_begin == k_end) return ADI_OK;
+    const long total = (long)nx * ny * (k_end - k_begin);
+    hipLaunchKernelGGL(k_birth, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_T, d_active, d_full, L, k_begin, k_end,
+                       Ts, d_newborn);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+static unsigned range_blocks(const Lay &L, int k0, int k1) { return (unsigned)(((long)L.nx * L.ny * (k1 - k0) + 255) / 256); }
+
+int adi_build_coeffs_planes(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, double dx, double rho,
+                            double cp, const int *h_mode, const double *h_scalar, const double *const *d_h_field,
+                            const int *q_mode, const double *q_scalar, const double *const *d_q_field,
+                            double *const *d_coeff, double *const *d_qflux, int k_begin, int k_end, void *stream)
 {
     ADI_REQUIRE(d_mask && h_mode && h_scalar && q_mode && q_scalar && d_coeff && d_qflux, "adi_build_coeffs: null argument");
     Lay L;
     if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    ADI_REQUIRE(k_begin >= 0 && k_end <= nz && k_begin <= k_end, "adi_build_coeffs_planes: bad plane range [%d, %d)", k_begin, k_end);
     FaceSpec h, q;
     for (int f = 0; f < 6; ++f) {
         h.mode[f] = h_mode[f]; h.scalar[f] = h_scalar[f]; h.field[f] = d_h_field ? d_h_field[f] : nullptr;
@@ -402,10 +497,34 @@ int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, long plane_s
         ADI_REQUIRE(q.mode[f] != ADI_FACE_FIELD || q.field[f], "adi_build_coeffs: missing q field for face %d", f);
     }
     for (int a = 0; a < 3; ++a) ADI_REQUIRE(d_coeff[a] && d_qflux[a], "adi_build_coeffs: null output");
+    if (k_begin == k_end) return ADI_OK;
     // A = dx*dx, V = dx**3 (CPython float_pow -> libm pow), Ccell = rho*cp*V: adi3d_numba_coeff.py:66-68
     const double A = dx * dx, V = pow(dx, 3.0), Ccell = rho * cp * V;
-    hipLaunchKernelGGL(k_build_coeffs, dim3(cell_blocks(L)), dim3(256), 0, as_stream(stream), d_mask, L, A, Ccell, h,
-                       q, d_coeff[0], d_coeff[1], d_coeff[2], d_qflux[0], d_qflux[1], d_qflux[2]);
+    hipLaunchKernelGGL(k_build_coeffs, dim3(range_blocks(L, k_begin, k_end)), dim3(256), 0, as_stream(stream), d_mask, L,
+                       k_begin, k_end, A, Ccell, h, q, d_coeff[0], d_coeff[1], d_coeff[2], d_qflux[0], d_qflux[1], d_qflux[2]);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, double dx, double rho,
+                     double cp, const int *h_mode, const double *h_scalar, const double *const *d_h_field,
+                     const int *q_mode, const double *q_scalar, const double *const *d_q_field,
+                     double *const *d_coeff, double *const *d_qflux, void *stream)
+{
+    return adi_build_coeffs_planes(d_mask, nx, ny, nz, plane_stride, dx, rho, cp, h_mode, h_scalar, d_h_field, q_mode,
+                                   q_scalar, d_q_field, d_coeff, d_qflux, 0, nz, stream);
+}
+
+int adi_build_nbr_flags_planes(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, uint8_t *d_flags,
+                               int k_begin, int k_end, void *stream)
+{
+    ADI_REQUIRE(d_mask && d_flags, "adi_build_nbr_flags: null argument");
+    Lay L;
+    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
+    ADI_REQUIRE(k_begin >= 0 && k_end <= nz && k_begin <= k_end, "adi_build_nbr_flags_planes: bad plane range [%d, %d)", k_begin, k_end);
+    if (k_begin == k_end) return ADI_OK;
+    hipLaunchKernelGGL(k_build_flags, dim3(range_blocks(L, k_begin, k_end)), dim3(256), 0, as_stream(stream), d_mask, L, k_begin,
+                       k_end, d_flags);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }
@@ -413,13 +532,9 @@ int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, long plane_s
 int adi_build_nbr_flags(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, uint8_t *d_flags,
                         void *stream)
 {
-    ADI_REQUIRE(d_mask && d_flags, "adi_build_nbr_flags: null argument");
-    Lay L;
-    if (int rc = make_lay(nx, ny, nz, plane_stride, &L)) return rc;
-    hipLaunchKernelGGL(k_build_flags, dim3(cell_blocks(L)), dim3(256), 0, as_stream(stream), d_mask, L, d_flags);
-    ADI_CHECK_LAUNCH();
-    return ADI_OK;
+    return adi_build_nbr_flags_planes(d_mask, nx, ny, nz, plane_stride, d_flags, 0, nz, stream);
 }
+
 int adi_explicit_rhs_planes(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride,
                             double dx, double dt, double kappa, double theta, double *d_R0, int i_begin, int i_end,
                             void *stream)

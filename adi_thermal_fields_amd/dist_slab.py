@@ -64,6 +64,8 @@ class TorchDistComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.bytes_sent = 0          # payload this rank has handed to the transport (bench.py reports it per step)
+        self.n_exchanges = 0
 
     def exchange_planes(self, send_lo, send_hi, recv_lo, recv_hi):
         """send_lo -> rank-1 (received there as recv_hi), send_hi -> rank+1 (received there as recv_lo)."""
@@ -72,14 +74,18 @@ class TorchDistComm:
         if self.rank > 0:
             ops.append(dist.P2POp(dist.isend, send_lo, self.rank - 1, self.group))
             ops.append(dist.P2POp(dist.irecv, recv_lo, self.rank - 1, self.group))
+            self.bytes_sent += send_lo.numel() * send_lo.element_size()
         if self.rank < self.world - 1:
             ops.append(dist.P2POp(dist.isend, send_hi, self.rank + 1, self.group))
             ops.append(dist.P2POp(dist.irecv, recv_hi, self.rank + 1, self.group))
+            self.bytes_sent += send_hi.numel() * send_hi.element_size()
         if ops:
+            self.n_exchanges += 1
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
 
     def all_gather(self, out, inp):
+        self.bytes_sent += inp.numel() * inp.element_size() * (self.world - 1)
         self.dist.all_gather_into_tensor(out, inp, group=self.group)
 
 

@@ -98,7 +98,7 @@ def run_layer_birth(backend, mask_full, dx, mat_args, h, Tinf, Ts, theta, cfl, l
     def build_packs():
         return backend.precompute_coeff_packs_unified(grid, mat, dir_mask=None, dir_value=None, neumann=None,
                                                       robin_h=robin, robin_Tinf=Tinf)
-    packs = build_packs()
+    packs = None
     nsteps = 0
     next_birth, t_now = 0, 0.0
 
@@ -114,13 +114,23 @@ def run_layer_birth(backend, mask_full, dx, mat_args, h, Tinf, Ts, theta, cfl, l
                 T = _step(backend, T, grid, mat, params, packs, Tinf)
         nsteps += nsub
 
-    # device loop: the full mask and the active mask live in HBM, a birth is three small tensor
-    # operations on the layer's planes plus the flags / pack rebuild kernels -- nothing crosses PCIe between output times
-    dev_loop = device_loop and device_resident and hasattr(grid, 'set_mask_device') and hasattr(T, 'fill_where')
+    # device loop: the full mask, the active mask, the field and the packs live in HBM.  A birth
+    # is ONE kernel on the layer's planes (newborn = full & ~active, T[newborn] = Ts, active |= full: adi_birth_planes),
+    # then the flags and the six coefficient arrays are rebuilt on the planes whose exposure can have changed (the layer
+    # and one plane either side) -- in place, no allocation, no host synchronisation: nothing crosses PCIe between
+    # output times and nothing waits for the device between births
+    dev_loop = device_loop and device_resident and hasattr(backend, 'BirthPacks') and hasattr(T, 'fill_where')
     if dev_loop:
         import torch
         d_full = grid.layout.to_layout(mask_full, torch.uint8)
         d_act = grid.layout.empty(torch.uint8, zero=True)
+        grid.set_mask_device(d_act, all_solid=False)
+        bpacks = backend.BirthPacks(grid, mat, robin_h=robin)
+        packs = bpacks.packs
+        plane_cells = np.asarray(mask_full).sum(axis=(0, 1)).astype(np.int64)      # newborn cells per plane, host-known
+        plane_born = np.zeros(nz, dtype=bool)
+    if not dev_loop:
+        packs = build_packs()
     n_active = 0
 
     def host_mask():
@@ -136,15 +146,14 @@ def run_layer_birth(backend, mask_full, dx, mat_args, h, Tinf, Ts, theta, cfl, l
             t_now = t_b
             ks, ke = layers[next_birth]
             if dev_loop:
-                born = d_full[:, :, ks:ke + 1]
-                act = d_act[:, :, ks:ke + 1]
-                newborn = (born != 0) & (act == 0)
-                nb = int(newborn.sum())
-                if nb:
-                    T.t[:, :, ks:ke + 1][newborn] = Ts          # T[newborn] = Ts (:489-493)
-                act |= born
-                n_active += nb
-                grid.set_mask_device(d_act)                     # :494-495 without the host round trip
+                backend.birth_planes(T, d_act, d_full, grid, ks, ke + 1, Ts)          # :489-493 + mask_act |= born
+                fresh = ~plane_born[ks:ke + 1]
+                n_active += int(plane_cells[ks:ke + 1][fresh].sum())
+                plane_born[ks:ke + 1] = True
+                grid.set_mask_device(d_act, ks - 1 if ks > 0 else 0, min(nz, ke + 2), all_solid=False)   # :494-495
+                packs = bpacks.update(ks - 1, ke + 2)                                 # :534, the planes that changed
+                next_birth += 1
+                continue
             else:
                 born = np.zeros_like(mask_full, dtype=bool)
                 born[:, :, ks:ke + 1] = mask_full[:, :, ks:ke + 1]

@@ -307,6 +307,23 @@ def main():
         kernels[nm] = dict(ms=round(float(mean_ms[i]), 4), bytes_per_cell=round(bytes_per_cell[nm], 3),
                            achieved_gbs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
 
+    # what every rank measured, so that the SCALE record shows what RCCL saw: the world size from the process group itself,
+    # every rank's stage times and the payload each rank handed to the transport per step
+    ranks_info = None
+    if world > 1 or force_dist:
+        comm = stepper.comm
+        mine = torch.tensor(list(mean_ms) + [float(getattr(comm, 'bytes_sent', 0)), float(getattr(comm, 'n_exchanges', 0)),
+                                             float(t1 - t0)], dtype=torch.float64, device=dev)
+        allr = torch.empty(dist.get_world_size() * mine.numel(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(dist.get_world_size(), -1).cpu().numpy()
+        nsteps_counted = a.steps + max(a.warmup, 1) + 2            # the counters run from construction (incl. self-check)
+        ranks_info = dict(world_size_from_process_group=dist.get_world_size(), backend=dist.get_backend(),
+                          stage_ms_per_rank={nm: [round(float(v), 4) for v in allr[:, i]] for i, nm in enumerate(stage_names)},
+                          loop_seconds_per_rank=[round(float(v), 4) for v in allr[:, nst + 2]],
+                          mbytes_sent_per_rank_total=[round(float(v) / 1e6, 2) for v in allr[:, nst]],
+                          exchanges_per_rank_total=[int(v) for v in allr[:, nst + 1]],
+                          note='byte / exchange counters cover %d steps (warm-up, self-check and timed loop)' % nsteps_counted)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -362,6 +379,7 @@ def main():
         roofline=dict(bound='hbm', kernel=dom, achieved=kernels[dom]['achieved_gbs'], peak=HBM_PEAK_GBS,
                       unit='GB/s', frac=kernels[dom]['frac'], traffic=traffic),
         kernels=kernels,
+        **({'ranks': ranks_info} if ranks_info is not None else {}),
     )
     if xs is not None:
         line['general_pack_sweeps_42B'] = xs

@@ -72,6 +72,19 @@ long adi_recommended_plane_stride(int ny, int nz);
 int adi_exposed_mask(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, int face,
                      uint8_t *d_exposed, void *stream);
 
+/* Exposed faces per plane k of axis 2, counted from the neighbour-flags digest (adi_build_nbr_flags): the count loop of
+ * quick_compare_layer_birth_robin_v3.py:97-108 (exposed x-/x+/y-/y+ faces of the 2-D section, the digital perimeter
+ * divided by dx) for every layer of a 3-D mask at once.  face_bits: bit f set = count face f (0..5 = x-, x+, y-, y+, z-,
+ * z+; 15 = the four lateral faces).  d_counts: nz unsigned 64-bit integers (zeroed here). */
+int adi_count_exposed_faces(const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride, int face_bits,
+                            unsigned long long *d_counts, void *stream);
+
+/* A layer birth in one pass over the planes [k_begin, k_end) of axis 2 (activate_layer, waam_from_stl_v7_mm.py:487-495):
+ * newborn = full & ~active; T[newborn] = Ts; active |= full.  *d_newborn (device, 64-bit) receives the number of
+ * newborn cells.  The caller then rebuilds the flags and the packs, as the reference's drivers do (:494-495, :534). */
+int adi_birth_planes(double *d_T, uint8_t *d_active, const uint8_t *d_full, int nx, int ny, int nz, long plane_stride,
+                     int k_begin, int k_end, double Ts, unsigned long long *d_newborn, void *stream);
+
 /*
  * precompute_coeff_packs_unified: adi3d_numba_coeff.py:57-118 / adi3d_gpu_coeff.py:50-110.
  * One pass over the grid writes the three Robin coefficient fields and the three Neumann flux fields:
@@ -85,6 +98,12 @@ int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, long plane_s
                      const int *h_mode, const double *h_scalar, const double *const *d_h_field,
                      const int *q_mode, const double *q_scalar, const double *const *d_q_field,
                      double *const *d_coeff, double *const *d_qflux, void *stream);
+/* ... restricted to the planes [k_begin, k_end) of axis 2 (in-place update of packs built earlier: see
+ * adi_build_nbr_flags_planes). */
+int adi_build_coeffs_planes(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, double dx, double rho,
+                            double cp, const int *h_mode, const double *h_scalar, const double *const *d_h_field,
+                            const int *q_mode, const double *q_scalar, const double *const *d_q_field,
+                            double *const *d_coeff, double *const *d_qflux, int k_begin, int k_end, void *stream);
 
 /*
  * Neighbour flags, the device-side digest of the mask every step kernel reads instead of the raw mask:
@@ -95,6 +114,10 @@ int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, long plane_s
  */
 int adi_build_nbr_flags(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride,
                         uint8_t *d_flags, void *stream);
+/* The same restricted to the planes [k_begin, k_end) of axis 2: after a layer birth only the planes of the layer and
+ * the one below / above it change (waam_from_stl_v7_mm.py:487-495 rebuilds everything; the result is the same). */
+int adi_build_nbr_flags_planes(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, uint8_t *d_flags,
+                               int k_begin, int k_end, void *stream);
 
 /* lap1D_x/y/z + R0 = Tn + dt*kappa*(1-theta)*(Lx+Ly+Lz): adi3d_numba_coeff.py:240-288, :298 */
 int adi_explicit_rhs(const double *d_T, const uint8_t *d_flags, int nx, int ny, int nz, long plane_stride,

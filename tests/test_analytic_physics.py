@@ -90,3 +90,61 @@ def test_physics_on_oracle(check):
 def test_physics_on_hip(check):
     import adi_thermal_fields_amd.adi3d_hip_coeff as hip
     check(hip, to_state=hip.to_device, to_host=lambda d: d.get())
+
+
+# ---- the reference's own analytic cases (quick_compare_dirichlet_robin.py, quick_compare_neumann_robin.py) ------------
+# finite-radius cylinder, side Robin, far end at ambient; closed forms in tests/analytic_series.py.  The scripts plot
+# these comparisons at nxr = 64, nz = 160; here they are asserted -- on the CPU oracle at nxr = 16 (seconds) and on the
+# HIP backend at the scripts' default grid.
+def _cylinder_case(api, kind, nxr, nz, bound_dirichlet=3.0, bound_neumann=0.1, **kw):
+    import analytic_series as an
+    R, h, Tinf, Ts, q0 = 0.02, 500.0, 20.0, 1000.0, 2.0e5
+    Bi = h * R / STEEL['k']
+    times = np.linspace(0.01, 5.0, 6)                      # the scripts' frame times
+    prof, dx = an.run_cylinder(api, kind, nxr, nz, times, STEEL, R=R, h_side=h, Tinf=Tinf, Ts=Ts, q0=q0, **kw)
+    errs = []
+    for i, tt in enumerate(times):
+        if kind == 'dirichlet':
+            # the Dirichlet cell centre is the heated surface: cell k sits at z = k dx
+            ana = an.dirichlet_step_axis(np.arange(nz) * dx, tt, ALPHA, R, Bi, Ts, Tinf)
+        else:
+            ana = an.neumann_heating_axis((np.arange(nz) + 0.5) * dx, tt, ALPHA, R, Bi, q0, STEEL['k'], Tinf)
+        errs.append(float(np.abs(prof[i] - ana).max()))
+    if kind == 'dirichlet':
+        # t >= 1 s: the thermal layer sqrt(alpha t) spans several cells (at t = 0.01 s it is a third of a cell at nxr = 16)
+        assert max(errs[1:]) <= bound_dirichlet, errs          # degrees C of a 980 degree step
+        assert prof.max() <= Ts + 1e-6 and prof.min() >= Tinf - 1e-6
+    else:
+        assert max(errs) <= bound_neumann, errs                 # degrees C of a ~33 degree rise
+        assert prof[-1, 0] > Tinf + 25.0                        # q0 > 0 heats the body
+    return errs
+
+
+@pytest.mark.parametrize('kind', ['dirichlet', 'neumann'])
+def test_cylinder_series_on_oracle(kind):
+    from oracle import adi_oracle as orc
+    _cylinder_case(orc, kind, 16, 40, bound_dirichlet=3.5, bound_neumann=0.25)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['dirichlet', 'neumann'])
+def test_cylinder_series_on_hip_default_grid(kind):
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    _cylinder_case(hip, kind, 64, 160, bound_dirichlet=2.0, bound_neumann=0.1, to_state=hip.to_device, to_host=lambda d: d.get())
+
+
+@pytest.mark.gpu
+def test_perimeter_ratio_correction_improves_the_neumann_case():
+    """quick_compare_layer_birth_robin_v3.py:95-112: the staircase cylinder has 4/pi times the true lateral area; scaling
+    h_side by gamma = true / digital perimeter (exposed faces counted on the device) brings the late-time error of the
+    Neumann case down by an order of magnitude"""
+    import analytic_series as an
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    R, nxr = 0.02, 64
+    dx = R / nxr
+    _, m2 = an.cylinder_mask(2 * nxr, 2 * nxr, 1, dx, R)
+    gamma = hip.perimeter_ratio(m2, dx, 2.0 * math.pi * R)
+    assert abs(gamma - math.pi / 4.0) < 2e-3, gamma
+    raw = _cylinder_case(hip, 'neumann', nxr, 160, to_state=hip.to_device, to_host=lambda d: d.get())
+    cor = _cylinder_case(hip, 'neumann', nxr, 160, to_state=hip.to_device, to_host=lambda d: d.get(), h_scale=gamma)
+    assert cor[-1] < 0.2 * raw[-1] and cor[-1] < 5e-3, (raw, cor)

@@ -85,3 +85,32 @@ def test_vtk_writers(tmp_path):
     q = str(tmp_path / 'f.npy')
     fio.write_npy(q, dev)
     assert np.array_equal(np.load(q), T2)
+
+
+def test_exposed_face_count_and_perimeter_ratio():
+    """device exposed-face count (adi_count_exposed_faces) against the cell-by-cell count of
+    quick_compare_layer_birth_robin_v3.py:97-108: bit-exact integers on random, disk and edge-touching sections; the
+    per-layer form against the same count applied to every plane of a 3-D mask, for the lateral and for all six faces"""
+    import math
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from oracle import perimeter_oracle as ref
+    from oracle import adi_oracle as orc
+    rng = np.random.default_rng(4)
+    secs = [rng.random((13, 9)) > 0.4, np.ones((5, 7), bool), np.zeros((4, 4), bool), rng.random((1, 17)) > 0.3]
+    xs = np.arange(40) + 0.5 - 20
+    secs.append(np.sqrt(xs[:, None] ** 2 + xs[None, :] ** 2) <= 17.3)
+    for m in secs:
+        assert hip.count_exposed_faces(m) == ref.count_exposed_faces(m)
+    with pytest.raises(ValueError):
+        hip.perimeter_ratio(np.zeros((4, 4), bool), 1e-3, 1.0)
+    g = hip.perimeter_ratio(secs[-1], 1.0, 2.0 * math.pi * 17.3)
+    assert abs(g - math.pi / 4.0) < 0.02
+    m3 = rng.random((11, 10, 23)) > 0.35
+    lat = hip.exposed_faces_per_layer(m3)
+    assert lat.dtype == np.int64 and lat.shape == (23,)
+    assert [int(v) for v in lat] == [ref.count_exposed_faces(m3[:, :, k]) for k in range(23)]
+    allf = hip.exposed_faces_per_layer(m3, faces=('x-', 'x+', 'y-', 'y+', 'z-', 'z+'))
+    want = sum(orc.exposed_mask(m3, f).sum(axis=(0, 1)) for f in ('x-', 'x+', 'y-', 'y+', 'z-', 'z+'))
+    assert np.array_equal(allf, want)
+    with pytest.raises(ValueError):
+        hip.exposed_faces_per_layer(m3, faces=('w+',))

@@ -245,3 +245,48 @@ def test_layer_birth_long_segments_use_graph_and_match_oracle():
     got, n2 = waam.run_layer_birth(hip, mask, dx, STEEL, 40.0, 20.0, 1000.0, 0.5, 0.25, layers, times, outs)
     assert n1 == n2 and n1 / len(layers) >= waam.GRAPH_MIN_NSUB
     assert rel_linf(got, want) <= 1e-10, rel_linf(got, want)
+
+
+@pytest.mark.gpu
+def test_birth_kernel_and_incremental_packs_equal_the_full_rebuild():
+    """adi_birth_planes + the plane-range rebuild of flags and coefficient arrays (BirthPacks.update) against the
+    reference's sequence on the host (newborn = full & ~active; T[newborn] = Ts; active |= full; full pack rebuild,
+    waam_from_stl_v7_mm.py:487-495, :534): identical masks, fields, newborn counts, and BIT-identical flags and packs
+    after every birth -- including births out of order and a layer born twice"""
+    import torch
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    waam, mask, layers, dx, times = _setup((20, 18, 26))
+    nx, ny, nz = mask.shape
+    mat = hip.Material(*STEEL)
+    robin = {f: 40.0 for f in ('x-', 'x+', 'y-', 'y+', 'z-', 'z+')}
+    grid = hip.Grid3D(nx, ny, nz, dx, np.zeros_like(mask))
+    L = grid.layout
+    d_full = L.to_layout(mask, torch.uint8)
+    d_act = L.empty(torch.uint8, zero=True)
+    grid.set_mask_device(d_act, all_solid=False)
+    bp = hip.BirthPacks(grid, mat, robin_h=robin)
+    rng = np.random.default_rng(1)
+    T0 = rng.uniform(20.0, 300.0, mask.shape)
+    T = hip.to_device(T0)
+    T_host, act_host = T0.copy(), np.zeros_like(mask)
+    order = list(range(len(layers)))
+    order[2], order[5] = order[5], order[2]
+    order.insert(4, order[1])                                        # a layer that is born again: nothing is newborn
+    ref_grid = hip.Grid3D(nx, ny, nz, dx, act_host)
+    for li in order:
+        ks, ke = layers[li]
+        cnt = hip.birth_planes(T, d_act, d_full, grid, ks, ke + 1, 1000.0)
+        grid.set_mask_device(d_act, max(0, ks - 1), min(nz, ke + 2), all_solid=False)
+        packs = bp.update(ks - 1, ke + 2)
+        born = np.zeros_like(mask); born[:, :, ks:ke + 1] = mask[:, :, ks:ke + 1]
+        newborn = born & ~act_host
+        T_host[newborn] = 1000.0
+        act_host |= born
+        assert int(cnt.item()) == int(newborn.sum())
+        assert np.array_equal(grid.mask, act_host) and np.array_equal(T.get(), T_host)
+        ref_grid.mask = act_host
+        ref_packs = hip.precompute_coeff_packs_unified(ref_grid, mat, robin_h=robin)
+        assert torch.equal(grid.d_flags, ref_grid.d_flags)
+        for a in range(3):
+            assert np.array_equal(packs[a].coeff, ref_packs[a].coeff), (li, a)
+            assert np.array_equal(packs[a].qflux, ref_packs[a].qflux), (li, a)
