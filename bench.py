@@ -40,7 +40,7 @@ def parse():
                     help="cart: the headline 512^3 Cartesian workload (default); cyl: BASELINE.json configs[3], the "
                          "cylindrical 128 x 256 x 512 BE step on one GPU (replicas only at N > 1: it does not shard)")
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
-    ap.add_argument('--cpu-n', type=int, default=256, help='edge of the bounded CPU-baseline sample')
+    ap.add_argument('--cpu-n', type=int, default=512, help='edge of the CPU-baseline sample (512: BASELINE.md section 3)')
     ap.add_argument('--force-dist', action='store_true',
                     help='one GPU only: run the slab code path over a real single-rank RCCL process group (checks the '
                          'torch.distributed plumbing: init, all_gather, all_reduce, barrier); marked in the JSON line')
@@ -50,9 +50,11 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(n, seed=0):
-    """The oracle (oracle/adi_oracle.c, a port of the reference's Numba path) timed on this host's cores on a
-    bounded sample of the same workload.  Returns (single-thread dict, all-cores dict)."""
+def cpu_baseline(n, seed=0, steps_1t=3, steps_all=9):
+    """The oracle (oracle/adi_oracle.c, a port of the reference's Numba path) timed on this host's cores on a bounded
+    sample of the same workload: n^3 cells (default 512) x `steps_1t` steps on ONE thread -- the
+    reference's kernels are serial -- and x `steps_all` steps on all cores (OpenMP over lines, working set first-touched
+    in parallel).  Returns (single-thread dict, all-cores dict)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from oracle import adi_oracle as orc
     shape = (n, n, n)
@@ -60,19 +62,21 @@ def cpu_baseline(n, seed=0):
     mat = orc.Material(7800.0, 490.0, 54.0)
     alpha = mat.k / (mat.rho * mat.cp)
     prm = orc.Params(200.0 * grid.dx ** 2 / alpha, 0.5)
-    packs = orc.precompute_coeff_packs_unified(grid, mat, robin_h=500.0)
+    packs = orc.precompute_coeff_packs_unified(grid, mat, robin_h=500.0, _share=True)
     T0 = np.random.default_rng(seed).uniform(20.0, 1000.0, shape)
     out = []
-    for omp, steps in ((False, 8), (True, 40)):
-        orc.adi_run(T0, grid, mat, prm, packs, Tinf=20.0, nsteps=1, omp=omp)   # warm (page faults, OpenMP pool)
+    for omp, steps in ((False, steps_1t), (True, steps_all)):
+        if omp:
+            orc.adi_run(T0, grid, mat, prm, packs, Tinf=20.0, nsteps=1, omp=True)   # warm the OpenMP pool
         t0 = time.perf_counter()
         orc.adi_run(T0, grid, mat, prm, packs, Tinf=20.0, nsteps=steps, omp=omp)
         dt = time.perf_counter() - t0
         cells_per_s = steps * n ** 3 / dt
         out.append(dict(value=cells_per_s / 512 ** 3, unit='steps/s (512^3-cell equivalent)',
                         cores=(os.cpu_count() if omp else 1), kind='port',
-                        sample='%d^3 cells x %d steps of the same Robin workload, %.1f s, oracle/adi_oracle%s.c'
-                               % (n, steps, dt, '_omp' if omp else ''),
+                        sample='%d^3 cells x %d steps of the same Robin workload, %.1f s, oracle/adi_oracle%s.c%s'
+                               % (n, steps, dt, '_omp' if omp else '',
+                                  ' (time includes the parallel first-touch copy of the working set)' if omp else ''),
                         cell_updates_per_s=cells_per_s))
     return out
 
