@@ -87,6 +87,7 @@ SIGNATURES = {
     'adi_count_exposed_faces': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p, c_void_p]),
     'adi_birth_planes': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_int, c_double, c_void_p,
                                  c_void_p]),
+    'adi_copy_planes': (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_int, c_void_p]),
     'adi_masked_fill': (c_int, [c_void_p, c_void_p, c_size_t, c_double, c_void_p]),
     'adi_mask_or': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'adi_cyl_plan_create': (c_int, [c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double, c_double, c_double,

@@ -93,17 +93,36 @@ class Layout:
             src = a.to(device=_device())
             if dtype == torch.uint8 and src.dtype == torch.bool:
                 src = src.to(torch.uint8)
+            assert tuple(src.shape) == self.shape, (tuple(src.shape), self.shape)
+            out = self.empty(dtype, zero=(dtype == torch.uint8 and self.sx != self.ny * self.nz))
+            out.copy_(src.to(dtype) if src.dtype != dtype else src)
+            return out
+        arr = np.asarray(a)
+        if dtype == torch.uint8:
+            arr = np.ascontiguousarray(arr.astype(np.bool_, copy=False)).view(np.uint8)
         else:
-            arr = np.asarray(a)
-            if dtype == torch.uint8:
-                arr = np.ascontiguousarray(arr.astype(np.bool_, copy=False)).view(np.uint8)
-            else:
-                arr = np.ascontiguousarray(arr, dtype=np.float64)   # fp32 fields are up-cast (waam --precision float32)
-            src = torch.from_numpy(arr)
-        assert tuple(src.shape) == self.shape, (tuple(src.shape), self.shape)
+            arr = np.ascontiguousarray(arr, dtype=np.float64)   # fp32 fields are up-cast (waam --precision float32)
+        assert tuple(arr.shape) == self.shape, (tuple(arr.shape), self.shape)
         out = self.empty(dtype, zero=(dtype == torch.uint8 and self.sx != self.ny * self.nz))
-        out.copy_(src.to(dtype) if src.dtype != dtype else src)
+        # every plane of the dense host array into its (padded) device plane: ONE 2-D DMA, no staging tensor
+        es = arr.itemsize
+        check(lib.adi_copy_planes(_p(out), self.sx * es, ctypes.c_void_p(arr.ctypes.data), self.ny * self.nz * es,
+                                  self.ny * self.nz * es, self.nx, 1, _stream()))
+        torch.cuda.current_stream().synchronize()     # the caller may touch its array as soon as we return
         return out
+
+    def to_host(self, t):
+        """native-layout device tensor -> C-order NumPy array (a new array, as the reference's step returns one).  The
+        array lives in page-locked memory from torch's caching host allocator: the transfer is one 2-D DMA at PCIe
+        rate, and in a driver's `T = step(T, ...)` loop the block of the array dropped a step ago is reused, so no
+        fresh pages are faulted in (1 GiB of first-touch page faults cost more than the transfer itself)."""
+        assert self.is_native(t)
+        host = torch.empty(self.shape, dtype=t.dtype, pin_memory=True)
+        es = t.element_size()
+        check(lib.adi_copy_planes(ctypes.c_void_p(host.data_ptr()), self.ny * self.nz * es, _p(t), self.sx * es,
+                                  self.ny * self.nz * es, self.nx, 0, _stream()))
+        torch.cuda.current_stream().synchronize()
+        return host.numpy()
 
 
 class DeviceField:
@@ -120,6 +139,10 @@ class DeviceField:
     dtype = np.dtype(np.float64)
 
     def get(self):
+        L = Layout(*tuple(self.t.shape), sx=self.t.stride(0)) if self.t.dim() == 3 and self.t.stride(1) == self.t.shape[2] \
+            and self.t.stride(2) == 1 and self.t.stride(0) >= self.t.shape[1] * self.t.shape[2] else None
+        if L is not None and L.is_native(self.t):
+            return L.to_host(self.t)
         return self.t.cpu().contiguous().numpy()
 
     def __array__(self, dtype=None, copy=None):
@@ -479,7 +502,7 @@ def _wrap(t, kind):
         return DeviceField(t)
     if kind == 'torch':
         return t
-    return t.cpu().contiguous().numpy()
+    return DeviceField(t).get()
 
 
 def adi_explicit_rhs(Tn, grid, mat, params):

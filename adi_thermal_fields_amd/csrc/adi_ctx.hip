@@ -277,6 +277,20 @@ int adi_ctx_step(adi_ctx *c, double rho, double cp, double k, double dt, double 
     return ADI_OK;
 }
 
+int adi_copy_planes(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t plane_bytes, size_t nplanes,
+                    int to_device, void *stream)
+{
+    ADI_REQUIRE(dst && src, "adi_copy_planes: null argument");
+    ADI_REQUIRE(dst_pitch >= plane_bytes && src_pitch >= plane_bytes, "adi_copy_planes: pitch smaller than a plane");
+    if (plane_bytes == 0 || nplanes == 0) return ADI_OK;
+    const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+    if (dst_pitch == plane_bytes && src_pitch == plane_bytes)
+        ADI_HIP_TRY(hipMemcpyAsync(dst, src, plane_bytes * nplanes, kind, as_stream(stream)));
+    else
+        ADI_HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, plane_bytes, nplanes, kind, as_stream(stream)));
+    return ADI_OK;
+}
+
 int adi_ctx_last_step_ms(adi_ctx *c, float *ms)
 {
     ADI_REQUIRE(c && ms, "adi_ctx_last_step_ms: null argument");

@@ -57,6 +57,12 @@ const char *adi_last_error(void);
 int         adi_device_count(int *count);
 /* name: caller buffer of >= 256 bytes; cu_count / hbm_bytes / lds_per_cu may be NULL */
 int         adi_device_info(int device, char *name, int *cu_count, size_t *hbm_bytes, size_t *lds_per_cu);
+/* The constructors of the reference copy their array arguments and the step returns a new array
+ * (adi3d_numba_coeff.py:18, :31-36, :135, :302): with HOST arrays at the boundary that is one transfer of every plane
+ * in each direction.  nplanes planes of plane_bytes each, src_pitch / dst_pitch bytes apart (the device layout pads its
+ * planes, the host array is dense), as ONE 2-D DMA on `stream`; to_device: 1 = host -> device, 0 = device -> host. */
+int         adi_copy_planes(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t plane_bytes,
+                            size_t nplanes, int to_device, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stateless device entry points (caller-owned device memory).
