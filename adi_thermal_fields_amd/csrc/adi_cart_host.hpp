@@ -76,15 +76,17 @@ inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok,
             }
         }
     }
-    if (P.Mf == 0) while (lines * P.Lpg < 256) lines <<= 1;
+    if (P.Mf == 0) {
+        while (lines * P.Lpg < 256) lines <<= 1;
+    }
     P.lines_g = lines;
     P.tiles_inner_g = (g.n_inner + lines - 1) / lines;
     P.ntiles_g = (long)P.tiles_inner_g * g.n_outer;
-    P.lds_g = (size_t)7 * lines * (P.Lpg + 1) * sizeof(double);
+    P.lds_g = (size_t)7 * lines * (P.Lpg + 1) * sizeof(double) + (size_t)lines * P.Lpg * 16;   // + byte-transposition strips
     if (P.Mf) {
         P.tiles_inner_f = (g.n_inner + P.lines_f - 1) / P.lines_f;
         P.ntiles_f = (long)P.tiles_inner_f * g.n_outer;
-        P.lds_f = (size_t)7 * P.lines_f * (P.Lpf + 1) * sizeof(double);
+        P.lds_f = (size_t)7 * P.lines_f * (P.Lpf + 1) * sizeof(double) + (size_t)P.lines_f * P.Lpf * P.Mf;   // + byte strips
     }
     return P;
 }

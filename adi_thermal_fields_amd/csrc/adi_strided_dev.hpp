@@ -16,13 +16,41 @@ template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
 __device__ __forceinline__ void load_segment_raw(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    const LineGeom &g, long base, int r0, bool active, const SweepScal &s, SegRaw<M> &R, const Fuse &fz = Fuse())
+    const LineGeom &g, long base, int r0, bool active, const SweepScal &s, SegRaw<M> &R, const Fuse &fz = Fuse(),
+    uint8_t *bstrip = nullptr)
 {
+    // bstrip != nullptr (block-uniform; M == 8, 8-line tiles, whole tile, 8-byte aligned byte arrays): the flag and
+    // Dirichlet bytes of a segment -- 8 rows x 8 lines -- are fetched as ONE 8-byte load per lane (lane kk takes row kk)
+    // and transposed through a wave-private LDS strip, instead of 8 + 8 single-byte loads per thread.  These kernels
+    // are bound by the issue rate of the vector-memory pipe (SQ_WAIT_INST_ANY 30 % of the wave cycles at 56 memory
+    // instructions per 8 cells), not by bytes.
+    unsigned long long dpk = 0;
+    if (bstrip != nullptr) {
+        if constexpr (M == 8) {
+            const int kk = threadIdx.x & 7;
+            const long prow = base - kk + (long)(r0 + kk) * g.stride;       // row r0+kk, first line of the tile
+            const unsigned long long fq = *reinterpret_cast<const unsigned long long *>(flags + prow);
+            unsigned long long dq = 0;
+            if (HAS_DIR) dq = *reinterpret_cast<const unsigned long long *>(dmask + prow);
+            uint8_t *st = bstrip + (threadIdx.x >> 3) * (HAS_DIR ? 128 : 64);   // this segment's strip: [line][row]
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                st[l * 8 + kk] = (uint8_t)(fq >> (8 * l));
+                if (HAS_DIR) st[64 + l * 8 + kk] = (uint8_t)(dq >> (8 * l));
+            }
+            wave_lds_fence();
+            const unsigned long long fpk = *reinterpret_cast<const unsigned long long *>(st + kk * 8);
+            if (HAS_DIR) dpk = *reinterpret_cast<const unsigned long long *>(st + 64 + kk * 8);
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < M; ++r) R.fb[r] = (unsigned)(fpk >> (8 * r)) & 0xffu;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < M; ++r) {
         const bool ok = active && (r0 + r) < g.n;
         const long p = base + (long)(r0 + r) * g.stride;
-        R.fb[r] = ok ? flags[p] : 0u;
+        if (bstrip == nullptr) R.fb[r] = ok ? flags[p] : 0u;
         R.vin[r] = ok ? in[p] : 0.0;
     }
     if (FUSE) {
@@ -50,7 +78,7 @@ __device__ __forceinline__ void load_segment_raw(
         const long p = base + (long)(r0 + r) * g.stride;
         const bool need = ok && (!s.sparse || axis_exposed(R.fb[r], g.lbit));
         R.dirb[r] = false;
-        if (HAS_DIR) R.dirb[r] = ok && dmask[p] != 0;
+        if (HAS_DIR) R.dirb[r] = (bstrip != nullptr) ? (((dpk >> (8 * r)) & 0xffull) != 0) : (ok && dmask[p] != 0);
         R.vco[r] = need ? coeff[p] : 0.0;
         R.vq[r] = (HAS_Q && need) ? qf[p] : 0.0;
         R.vdv[r] = (HAS_DIR && ok && (!s.sparse || R.dirb[r])) ? dval[p] : 0.0;
@@ -112,13 +140,37 @@ __device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in_
     return kind != SEG_NONE;
 }
 
+// Flag (or Dirichlet) bytes of a whole segment of a 16-line tile -- M rows x 16 lines -- as ONE 16-byte load per lane (lane
+// kk < M takes row kk of the segment) transposed through a wave-private LDS strip [line][row]: lane kk gets the bytes of
+// its M rows packed four per register.  Replaces M single-byte loads per thread: the strided kernels are bound by the
+// issue rate of the vector-memory pipe, not by bytes (SQ_WAIT_INST_ANY, profiles/r02_*).  `bt`: the tile's first byte
+// of row 0 of the line (16-byte aligned rows: host / block-uniform check); voff_row0: r0*stride (elements), kk = lane & 15.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int M>
+__device__ __forceinline__ void load_bytes_packed16(const uint8_t *bt, unsigned voff_row0, unsigned stride, int kk, uint8_t *strip,
+                                                    unsigned (&w)[M / 4])
+{
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)bt, 0, 0x7fffffff, 0x00020000);
+    if (kk < M) {
+        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rB, voff_row0 + (unsigned)kk * stride, 0u, 0);
+#pragma unroll
+        for (int l = 0; l < 16; ++l) strip[l * M + kk] = (uint8_t)((q[l >> 2] >> (8 * (l & 3))) & 0xffu);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < M / 4; ++i) w[i] = reinterpret_cast<const unsigned *>(strip + kk * M)[i];
+    wave_lds_fence();
+}
+template <int M>
+__device__ __forceinline__ unsigned packed_byte(const unsigned (&w)[M / 4], int r) { return (w[r >> 2] >> (8 * (r & 3))) & 0xffu; }
+
 // The same for whole tiles (block-uniform precondition: every lane active, every thread owns M rows), buffer
 // addressing: scalar row offsets, one per-thread offset, no per-row predicates and no 64-bit address arithmetic.
 template <int M, bool HAS_DIR>
 __device__ __forceinline__ bool fast_segment_load_buf(const double *__restrict__ in_t, const uint8_t *__restrict__ flags_t,
                                                       const uint8_t *__restrict__ dmask_t, const LineGeom &g, unsigned voff,
                                                       double (&d)[M], unsigned &f0, unsigned &fS, bool &dirS, int &kind,
-                                                      int &Lm)
+                                                      int &Lm, uint8_t *strip = nullptr)
 {
     const unsigned FULL = 1u | (3u << g.lbit), ROW0 = 1u | (2u << g.lbit);
     const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void *)in_t, 0, 0x7fffffff, 0x00020000);
@@ -127,9 +179,18 @@ __device__ __forceinline__ bool fast_segment_load_buf(const double *__restrict__
     bool uni = true;
     unsigned inm = 0;
     f0 = 0; fS = 0;
+    unsigned fw[M >= 4 ? M / 4 : 1];
+    if constexpr (M % 4 == 0 && M <= 16) {
+        if (strip != nullptr) load_bytes_packed16<M>(flags_t, voff - (threadIdx.x & 15u), st, (int)(threadIdx.x & 15u), strip, fw);
+    }
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-        const unsigned f = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, ADI_LOAD_AUX);
+        unsigned f;
+        if constexpr (M % 4 == 0 && M <= 16) {
+            f = (strip != nullptr) ? packed_byte<M>(fw, r) : __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, ADI_LOAD_AUX);
+        } else {
+            f = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, ADI_LOAD_AUX);
+        }
         d[r] = buf_load_f64_once(rT, voff * 8u, (unsigned)r * st * 8u);
         inm |= (f & 1u) << r;
         if (r == 0) { f0 = f; uni = uni && ((f & ROW0) == ROW0); }
@@ -167,7 +228,7 @@ __device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict
                                                         const uint8_t *__restrict__ dmask_t, const LineGeom &g,
                                                         unsigned voff, int r0, int kk, long tbase, const Fuse &fz,
                                                         double (&d)[M], unsigned &f0, unsigned &fS, bool &dirS, int &kind,
-                                                        int &Lm)
+                                                        int &Lm, uint8_t *strip = nullptr)
 {
 #pragma clang fp contract(off)
     constexpr int LINES = 16;
@@ -184,9 +245,17 @@ __device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict
     // the per-thread register, where the descriptor's range check turns an address before or after the window into a
     // load of 0 -- such a neighbour does not exist and the flags byte says so.
     unsigned fb[M];
+    if (strip != nullptr) {
+        if constexpr (M % 4 == 0 && M <= 16) {
+            unsigned fw[M / 4];
+            load_bytes_packed16<M>(flags_t, voff - (threadIdx.x & 15u), (unsigned)g.stride, (int)(threadIdx.x & 15u), strip, fw);
+#pragma unroll
+            for (int r = 0; r < M; ++r) fb[r] = packed_byte<M>(fw, r);
+        }
+    }
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-        fb[r] = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * (unsigned)g.stride, ADI_LOAD_AUX);
+        if (strip == nullptr) fb[r] = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * (unsigned)g.stride, ADI_LOAD_AUX);
         d[r] = buf_load_f64(rT, vb, R0 + (unsigned)r * st8);
     }
     const unsigned vw = vb + R0;                                     // this thread's row 0, bytes from the window start

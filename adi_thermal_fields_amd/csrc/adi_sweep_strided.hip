@@ -41,7 +41,12 @@ __device__ __forceinline__ void strided_tile_general(
     double a[M], b[M], c[M], d[M];
     {
         SegRaw<M> R;
-        load_segment_raw<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R, fz);
+        // packed byte loads (see load_segment_raw): whole 8-line tiles of 8-row segments, 8-byte aligned byte rows
+        uint8_t *bstrip = nullptr;
+        if (M == 8 && LINES == 8 && !FUSE && (ti + 1) * LINES <= g.n_inner && Lp * M == g.n && (g.stride & 7) == 0 &&
+            ((to * g.outer_stride) & 7) == 0 && (((uintptr_t)flags | (uintptr_t)(HAS_DIR ? dmask : flags)) & 7) == 0)
+            bstrip = reinterpret_cast<uint8_t *>(sm + 7 * LINES * (Lp + 1));
+        load_segment_raw<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R, fz, bstrip);
 #pragma unroll
         for (int r = 0; r < M; ++r) assemble_one<M, HAS_DIR, HAS_Q>(R, r, g.lbit, s, a[r], b[r], c[r], d[r]);
     }
@@ -65,7 +70,7 @@ __device__ __forceinline__ void strided_tile_general(
     back_solve<M>(a, c, d, ip, xL, xS, x);
 #pragma unroll
     for (int r = 0; r < M; ++r)
-        if (active && (r0 + r) < g.n) out[base + (long)(r0 + r) * g.stride] = x[r];
+        if (active && (r0 + r) < g.n) out[base + (long)(r0 + r) * g.stride] = x[r];   // (nt stores: 5-10 % slower on the 64-byte row pieces of these tiles)
 }
 
 // GENERAL kernel: every tile (queue == nullptr) or the tiles a FAST kernel queued
@@ -126,6 +131,10 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
     const bool pad = r0 >= g.n;                    // this thread's segment lies beyond the end of the line
     int kind = SEG_NONE, Lm = 0;                   // segment class (classify_mixed) and length of a mixed run
     bool lane_fast;
+    // flag bytes through packed 16-byte loads (load_bytes_packed16): 16-line tiles whose byte rows are 16-byte aligned
+    uint8_t *strip = nullptr;
+    if (M % 4 == 0 && M <= 16 && LINES == 16 && (g.stride & 15) == 0 && (tbase & 15) == 0 && ((uintptr_t)flags & 15) == 0)
+        strip = reinterpret_cast<uint8_t *>(sm + 7 * LINES * (Lp + 1)) + (size_t)sg * (LINES * M);
     if constexpr (FUSE) {
         // whole tiles only (block-uniform): anything else goes to the GENERAL kernel before a single load is issued
         if (LINES != 16 || (ti + 1) * LINES > g.n_inner || g.n % M != 0) {
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
         const int r0e = pad ? 0 : r0;
         lane_fast = fast_segment_load_fused<M, HAS_DIR, MIXED>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g,
                                                                pad ? (unsigned)kk : voff, r0e, kk, tbase, fz, d, f0, fS, dirS,
-                                                               kind, Lm) || pad;
+                                                               kind, Lm, strip) || pad;
         if (pad) kind = SEG_PAD;
     } else {
         // whole tiles whose rows fit 31-bit byte offsets take the buffer-addressed loader (block-uniform choice)
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
                            (long)g.n * g.stride * 8 < 0x7fffffffL;
         if (whole)
             lane_fast = fast_segment_load_buf<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, d,
-                                                          f0, fS, dirS, kind, Lm);
+                                                          f0, fS, dirS, kind, Lm, strip);
         else
             lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
                                                       active, d, f0, fS, dirS, kind, Lm);
