@@ -22,7 +22,7 @@ namespace adi {
 #endif
 constexpr bool kBufStrided = ADI_BUF_STRIDED != 0;
 #ifndef ADI_FUSE_D
-#define ADI_FUSE_D 8     // rows of j-neighbour loads in flight per thread in the fused FAST kernels (2: 0.77 ms, 4: 0.70, 8: 0.68, 16: 1.02 at 512^3)
+#define ADI_FUSE_D 10    // rows of j-neighbour loads in flight per thread in the fused FAST kernels (512^3: 2 0.77 ms, 4 0.70, 8 0.68; with the results pinned in the loader 8 0.64-0.66, 10 0.63-0.65, 12 0.67, 16 0.90: spills)
 #endif
 #ifndef ADI_FUSE_OCC
 #define ADI_FUSE_OCC 4   // waves per SIMD the fused FAST kernels are compiled for (4: two 512-thread workgroups per CU; 3 measures the same, 2 with deeper prefetch is slower)
@@ -379,6 +379,12 @@ __device__ __forceinline__ double buf_load_f64_once(__amdgpu_buffer_rsrc_t r, un
 {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, ADI_LOAD_AUX);
     return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ u32x2 as_u32x2(double x)
+{
+    u32x2 v;
+    v.x = (unsigned)__double2loint(x); v.y = (unsigned)__double2hiint(x);
+    return v;
 }
 __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x)
 {

@@ -42,10 +42,20 @@ struct Cond {
     double gF, aF, cF, gL, aL, cL;
 };
 
+// Off-diagonals of the assembled ADI rows take two values only -- the uniform -theta*gamma where the row couples to its
+// neighbour, 0 where it does not (line ends, cells outside the mask, Dirichlet rows; adi3d_gpu_coeff.py:173-187) -- so a
+// kernel that is short of registers keeps them as one bit per row and materialises the double where it is used: 2 VGPRs
+// instead of 2*M per off-diagonal, the same numbers in the same operations.
+struct MaskedCoef {
+    unsigned m;     // bit r: row r couples
+    double v;       // the coupling coefficient
+    __device__ __forceinline__ double operator[](int r) const { return ((m >> r) & 1u) ? v : 0.0; }
+};
+
 // phase 1.  a,b,c,d: the M rows (row M-1 = separator, untouched here).  ip: inverse pivots of the
-// top-down factorisation of the interior block, kept for phase 3.
-template <int M>
-__device__ __forceinline__ void condense(const double (&a)[M], const double (&b)[M], const double (&c)[M],
+// top-down factorisation of the interior block, kept for phase 3.  AV / CV: double[M] or MaskedCoef.
+template <int M, class AV, class CV>
+__device__ __forceinline__ void condense(const AV &a, const double (&b)[M], const CV &c,
                                          const double (&d)[M], double (&ip)[M - 1], Cond &k)
 {
     constexpr int MI = M - 1;
@@ -110,8 +120,8 @@ __device__ __forceinline__ double pcr_solve(double ra, double rb, double rc, dou
 }
 
 // phase 3.  x[M-1] = xS; interior rows from the stored inverse pivots.
-template <int M>
-__device__ __forceinline__ void back_solve(const double (&a)[M], const double (&c)[M], const double (&d)[M],
+template <int M, class AV, class CV>
+__device__ __forceinline__ void back_solve(const AV &a, const CV &c, const double (&d)[M],
                                            const double (&ip)[M - 1], double xL, double xS, double (&x)[M])
 {
     constexpr int MI = M - 1;

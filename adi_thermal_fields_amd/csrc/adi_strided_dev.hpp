@@ -85,6 +85,79 @@ __device__ __forceinline__ void load_segment_raw(
     }
 }
 
+// The same for whole tiles (block-uniform precondition: every lane active, every thread owns M rows, rows within 31-bit
+// byte offsets of the tile base) with buffer addressing: one descriptor per array based at the tile, the row offsets in
+// scalar registers, ONE 32-bit per-thread offset for every load and store -- the flat-addressed form above keeps a 64-bit
+// pointer per row alive from the first load to the last store (32 VGPRs at 8 rows), which is what pushed the 42 B/cell
+// kernel over its 128-VGPR budget into scratch.
+template <int M, bool HAS_DIR, bool HAS_Q>
+__device__ __forceinline__ void load_segment_raw_buf(
+    const double *__restrict__ in_t, const uint8_t *__restrict__ flags_t, const double *__restrict__ coeff_t,
+    const uint8_t *__restrict__ dmask_t, const double *__restrict__ dval_t, const double *__restrict__ qf_t,
+    const LineGeom &g, unsigned voff, const SweepScal &s, SegRaw<M> &R, uint8_t *bstrip)
+{
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void *)in_t, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void *)flags_t, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void *)coeff_t, 0, 0x7fffffff, 0x00020000);
+    const unsigned st = (unsigned)g.stride, st8 = st * 8u, vb = voff * 8u;
+    unsigned long long dpk = 0;
+    if (bstrip != nullptr) {
+        if constexpr (M == 8) {
+            // flag / Dirichlet bytes of the segment (8 rows x 8 lines) as ONE 8-byte load per lane, transposed in LDS
+            const unsigned kk = threadIdx.x & 7u;
+            const unsigned prow = voff - kk + kk * st;                          // row kk of the segment, first line of the tile
+            const u32x2 fq = __builtin_amdgcn_raw_buffer_load_b64(rF, prow, 0u, 0);
+            u32x2 dq = {0u, 0u};
+            if (HAS_DIR) {
+                const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)dmask_t, 0, 0x7fffffff, 0x00020000);
+                dq = __builtin_amdgcn_raw_buffer_load_b64(rM, prow, 0u, 0);
+            }
+            uint8_t *sp = bstrip + (threadIdx.x >> 3) * (HAS_DIR ? 128 : 64);   // this segment's strip: [line][row]
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                sp[l * 8 + kk] = (uint8_t)((l < 4 ? fq.x : fq.y) >> (8 * (l & 3)));
+                if (HAS_DIR) sp[64 + l * 8 + kk] = (uint8_t)((l < 4 ? dq.x : dq.y) >> (8 * (l & 3)));
+            }
+            wave_lds_fence();
+            const unsigned long long fpk = *reinterpret_cast<const unsigned long long *>(sp + kk * 8);
+            if (HAS_DIR) dpk = *reinterpret_cast<const unsigned long long *>(sp + 64 + kk * 8);
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < M; ++r) R.fb[r] = (unsigned)(fpk >> (8 * r)) & 0xffu;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        if (bstrip == nullptr) R.fb[r] = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, 0);
+        R.vin[r] = buf_load_f64(rT, vb, (unsigned)r * st8);
+    }
+    const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void *)(HAS_Q ? qf_t : coeff_t), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void *)(HAS_DIR ? dval_t : coeff_t), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)(HAS_DIR ? dmask_t : flags_t), 0, 0x7fffffff, 0x00020000);
+    if (!s.sparse) {                                // dense packs: every array in full, unconditional loads
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            R.dirb[r] = false;
+            if (HAS_DIR) R.dirb[r] = (bstrip != nullptr) ? (((dpk >> (8 * r)) & 0xffull) != 0)
+                                                         : (__builtin_amdgcn_raw_buffer_load_b8(rM, voff, (unsigned)r * st, 0) != 0);
+            R.vco[r] = buf_load_f64(rC, vb, (unsigned)r * st8);
+            R.vq[r] = HAS_Q ? buf_load_f64(rQ, vb, (unsigned)r * st8) : 0.0;
+            R.vdv[r] = HAS_DIR ? buf_load_f64(rV, vb, (unsigned)r * st8) : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            const bool need = axis_exposed(R.fb[r], g.lbit);
+            R.dirb[r] = false;
+            if (HAS_DIR) R.dirb[r] = (bstrip != nullptr) ? (((dpk >> (8 * r)) & 0xffull) != 0)
+                                                         : (__builtin_amdgcn_raw_buffer_load_b8(rM, voff, (unsigned)r * st, 0) != 0);
+            R.vco[r] = need ? buf_load_f64(rC, vb, (unsigned)r * st8) : 0.0;
+            R.vq[r] = (HAS_Q && need) ? buf_load_f64(rQ, vb, (unsigned)r * st8) : 0.0;
+            R.vdv[r] = (HAS_DIR && R.dirb[r]) ? buf_load_f64(rV, vb, (unsigned)r * st8) : 0.0;
+        }
+    }
+}
+
 template <int M, bool HAS_DIR, bool HAS_Q>
 __device__ __forceinline__ void assemble_one(const SegRaw<M> &R, int r, int lbit, const SweepScal &s, double &a,
                                              double &b, double &c, double &d)
@@ -310,6 +383,9 @@ __device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict
         } else {
             d[r] = explicit_cell(fb[r], cur, prev, nxt, jm, jp, km, kp, fz);
         }
+        // the result exists HERE: without this the optimiser merges the final `t + f*(..)` of the two paths and sinks it below
+        // the loop, keeping the state row and the Laplacian alive instead of one result (13 VGPRs more at 16 rows)
+        asm volatile("" : "+v"(d[r]));
         prev = cur;
         if (r + D < M) {
             __builtin_amdgcn_sched_barrier(0);
