@@ -29,6 +29,16 @@ def main():
     ms = e0.elapsed_time(e1) / K
     N = nr * nphi * nz
     print('cylindrical 128x256x512 BE: %.3f ms/step, %.1f steps/s, %.0f GB/s of 48 B/cell' % (ms, 1e3 / ms, 48 * N / ms / 1e6))
+    # the same loop replayed from a HIP graph (StagedCylStepper.run)
+    st = cyl.StagedCylStepper(g, mat, prm, rr, zbc)
+    for use_graph in (False, True):
+        st.run(T, 4, graph=use_graph)
+        torch.cuda.synchronize()
+        e0.record()
+        Tg = st.run(T, 200, graph=use_graph)
+        e1.record(); e1.synchronize()
+        ms = e0.elapsed_time(e1) / 200
+        print('  run(nsteps=200, graph=%s): %.3f ms/step, %.1f steps/s, %.0f GB/s of 48 B/cell' % (use_graph, ms, 1e3 / ms, 48 * N / ms / 1e6))
 
 
 if __name__ == '__main__':
