@@ -78,6 +78,7 @@ inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok,
     }
     if (P.Mf == 0) {
         while (lines * P.Lpg < 256) lines <<= 1;
+        // (16-line tiles in 1024-thread workgroups for the dense 8-row kernel: measured slower, 1.30 vs 1.245 ms on axis 0 at 512^3)
     }
     P.lines_g = lines;
     P.tiles_inner_g = (g.n_inner + lines - 1) / lines;

@@ -85,6 +85,30 @@ __device__ __forceinline__ void load_segment_raw(
     }
 }
 
+// Flag (or Dirichlet) bytes of a whole segment of a 16-line tile -- M rows x 16 lines -- as ONE 16-byte load per lane (lane
+// kk < M takes row kk of the segment) transposed through a wave-private LDS strip [line][row]: lane kk gets the bytes of
+// its M rows packed four per register.  Replaces M single-byte loads per thread: the strided kernels are bound by the
+// issue rate of the vector-memory pipe, not by bytes (SQ_WAIT_INST_ANY, profiles/r02_*).  `bt`: the tile's first byte
+// of row 0 of the line (16-byte aligned rows: host / block-uniform check); voff_row0: r0*stride (elements), kk = lane & 15.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int M>
+__device__ __forceinline__ void load_bytes_packed16(const uint8_t *bt, unsigned voff_row0, unsigned stride, int kk, uint8_t *strip,
+                                                    unsigned (&w)[M / 4])
+{
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)bt, 0, 0x7fffffff, 0x00020000);
+    if (kk < M) {
+        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rB, voff_row0 + (unsigned)kk * stride, 0u, 0);
+#pragma unroll
+        for (int l = 0; l < 16; ++l) strip[l * M + kk] = (uint8_t)((q[l >> 2] >> (8 * (l & 3))) & 0xffu);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < M / 4; ++i) w[i] = reinterpret_cast<const unsigned *>(strip + kk * M)[i];
+    wave_lds_fence();
+}
+template <int M>
+__device__ __forceinline__ unsigned packed_byte(const unsigned (&w)[M / 4], int r) { return (w[r >> 2] >> (8 * (r & 3))) & 0xffu; }
+
 // The same for whole tiles (block-uniform precondition: every lane active, every thread owns M rows, rows within 31-bit
 // byte offsets of the tile base) with buffer addressing: one descriptor per array based at the tile, the row offsets in
 // scalar registers, ONE 32-bit per-thread offset for every load and store -- the flat-addressed form above keeps a 64-bit
@@ -94,7 +118,7 @@ template <int M, bool HAS_DIR, bool HAS_Q>
 __device__ __forceinline__ void load_segment_raw_buf(
     const double *__restrict__ in_t, const uint8_t *__restrict__ flags_t, const double *__restrict__ coeff_t,
     const uint8_t *__restrict__ dmask_t, const double *__restrict__ dval_t, const double *__restrict__ qf_t,
-    const LineGeom &g, unsigned voff, const SweepScal &s, SegRaw<M> &R, uint8_t *bstrip)
+    const LineGeom &g, unsigned voff, const SweepScal &s, SegRaw<M> &R, uint8_t *bstrip, uint8_t *bstrip16 = nullptr)
 {
     const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void *)in_t, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void *)flags_t, 0, 0x7fffffff, 0x00020000);
@@ -126,9 +150,22 @@ __device__ __forceinline__ void load_segment_raw_buf(
             for (int r = 0; r < M; ++r) R.fb[r] = (unsigned)(fpk >> (8 * r)) & 0xffu;
         }
     }
+    if (bstrip16 != nullptr) {
+        if constexpr (M == 8) {
+            // 16-line tiles: the 8 rows x 16 lines of flag / Dirichlet bytes as one 16-byte load in 8 of the 16 lanes
+            const unsigned k16 = threadIdx.x & 15u;
+            uint8_t *sp = bstrip16 + (threadIdx.x >> 4) * 128;
+            unsigned fw[2], dw[2] = {0u, 0u};
+            load_bytes_packed16<8>(flags_t, voff - k16, st, (int)k16, sp, fw);
+            if (HAS_DIR) load_bytes_packed16<8>(dmask_t, voff - k16, st, (int)k16, sp, dw);
+#pragma unroll
+            for (int r = 0; r < M; ++r) R.fb[r] = packed_byte<8>(fw, r);
+            dpk = ((unsigned long long)dw[1] << 32) | dw[0];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-        if (bstrip == nullptr) R.fb[r] = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, 0);
+        if (bstrip == nullptr && bstrip16 == nullptr) R.fb[r] = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, 0);
         R.vin[r] = buf_load_f64(rT, vb, (unsigned)r * st8);
     }
     const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void *)(HAS_Q ? qf_t : coeff_t), 0, 0x7fffffff, 0x00020000);
@@ -138,7 +175,7 @@ __device__ __forceinline__ void load_segment_raw_buf(
 #pragma unroll
         for (int r = 0; r < M; ++r) {
             R.dirb[r] = false;
-            if (HAS_DIR) R.dirb[r] = (bstrip != nullptr) ? (((dpk >> (8 * r)) & 0xffull) != 0)
+            if (HAS_DIR) R.dirb[r] = (bstrip != nullptr || bstrip16 != nullptr) ? (((dpk >> (8 * r)) & 0xffull) != 0)
                                                          : (__builtin_amdgcn_raw_buffer_load_b8(rM, voff, (unsigned)r * st, 0) != 0);
             R.vco[r] = buf_load_f64(rC, vb, (unsigned)r * st8);
             R.vq[r] = HAS_Q ? buf_load_f64(rQ, vb, (unsigned)r * st8) : 0.0;
@@ -149,7 +186,7 @@ __device__ __forceinline__ void load_segment_raw_buf(
         for (int r = 0; r < M; ++r) {
             const bool need = axis_exposed(R.fb[r], g.lbit);
             R.dirb[r] = false;
-            if (HAS_DIR) R.dirb[r] = (bstrip != nullptr) ? (((dpk >> (8 * r)) & 0xffull) != 0)
+            if (HAS_DIR) R.dirb[r] = (bstrip != nullptr || bstrip16 != nullptr) ? (((dpk >> (8 * r)) & 0xffull) != 0)
                                                          : (__builtin_amdgcn_raw_buffer_load_b8(rM, voff, (unsigned)r * st, 0) != 0);
             R.vco[r] = need ? buf_load_f64(rC, vb, (unsigned)r * st8) : 0.0;
             R.vq[r] = (HAS_Q && need) ? buf_load_f64(rQ, vb, (unsigned)r * st8) : 0.0;
@@ -213,29 +250,6 @@ __device__ __forceinline__ bool fast_segment_load(const double *__restrict__ in_
     return kind != SEG_NONE;
 }
 
-// Flag (or Dirichlet) bytes of a whole segment of a 16-line tile -- M rows x 16 lines -- as ONE 16-byte load per lane (lane
-// kk < M takes row kk of the segment) transposed through a wave-private LDS strip [line][row]: lane kk gets the bytes of
-// its M rows packed four per register.  Replaces M single-byte loads per thread: the strided kernels are bound by the
-// issue rate of the vector-memory pipe, not by bytes (SQ_WAIT_INST_ANY, profiles/r02_*).  `bt`: the tile's first byte
-// of row 0 of the line (16-byte aligned rows: host / block-uniform check); voff_row0: r0*stride (elements), kk = lane & 15.
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-template <int M>
-__device__ __forceinline__ void load_bytes_packed16(const uint8_t *bt, unsigned voff_row0, unsigned stride, int kk, uint8_t *strip,
-                                                    unsigned (&w)[M / 4])
-{
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)bt, 0, 0x7fffffff, 0x00020000);
-    if (kk < M) {
-        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rB, voff_row0 + (unsigned)kk * stride, 0u, 0);
-#pragma unroll
-        for (int l = 0; l < 16; ++l) strip[l * M + kk] = (uint8_t)((q[l >> 2] >> (8 * (l & 3))) & 0xffu);
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < M / 4; ++i) w[i] = reinterpret_cast<const unsigned *>(strip + kk * M)[i];
-    wave_lds_fence();
-}
-template <int M>
-__device__ __forceinline__ unsigned packed_byte(const unsigned (&w)[M / 4], int r) { return (w[r >> 2] >> (8 * (r & 3))) & 0xffu; }
 
 // The same for whole tiles (block-uniform precondition: every lane active, every thread owns M rows), buffer
 // addressing: scalar row offsets, one per-thread offset, no per-row predicates and no 64-bit address arithmetic.

@@ -56,9 +56,16 @@ __device__ __forceinline__ void strided_tile_general(
         if (M == 8 && LINES == 8 && !FUSE && (ti + 1) * LINES <= g.n_inner && Lp * M == g.n && (g.stride & 7) == 0 &&
             ((to * g.outer_stride) & 7) == 0 && (((uintptr_t)flags | (uintptr_t)(HAS_DIR ? dmask : flags)) & 7) == 0)
             bstrip = reinterpret_cast<uint8_t *>(sm + 7 * LINES * (Lp + 1));
-        if (whole)
+        if (whole) {
+            // (16-line tiles of 8-row segments: the packed 16-byte form; rows and tile base 16-byte aligned)
+            uint8_t *bstrip16 = nullptr;
+            if (M == 8 && LINES == 16 && (g.stride & 15) == 0 && (tbase & 15) == 0 &&
+                (((uintptr_t)flags | (uintptr_t)(HAS_DIR ? dmask : flags)) & 15) == 0)
+                bstrip16 = reinterpret_cast<uint8_t *>(sm + 7 * LINES * (Lp + 1));
             load_segment_raw_buf<M, HAS_DIR, HAS_Q>(in + tbase, flags + tbase, coeff + tbase, HAS_DIR ? dmask + tbase : dmask,
-                                                    HAS_DIR ? dval + tbase : dval, HAS_Q ? qf + tbase : qf, g, voff, s, R, bstrip);
+                                                    HAS_DIR ? dval + tbase : dval, HAS_Q ? qf + tbase : qf, g, voff, s, R, bstrip,
+                                                    bstrip16);
+        }
         else
             load_segment_raw<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R, fz, bstrip);
 #pragma unroll
