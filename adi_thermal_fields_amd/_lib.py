@@ -93,6 +93,9 @@ SIGNATURES = {
     'adi_cyl_plan_create': (c_int, [c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double, c_double, c_double,
                                     c_double, c_double, c_double, c_int, c_int, c_double, c_double, c_double,
                                     c_double, c_double, c_double, c_void_pp]),
+    'adi_cyl_plan_create_annular': (c_int, [c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double, c_double, c_double,
+                                            c_double, c_double, c_double, c_double, c_int, c_int, c_double, c_double, c_double,
+                                            c_double, c_double, c_double, c_void_pp]),
     'adi_cyl_plan_destroy': (c_int, [c_void_p]),
     'adi_cyl_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_double, c_double, c_void_p]),

@@ -21,11 +21,15 @@ __all__ = ['StagedCylStepper', 'GridCyl', 'Material', 'Params', 'RobinR', 'ZBC',
 
 
 class GridCyl:  # adi3d_cyl_phi_v3.py:33-43
-    def __init__(self, nr, nphi, nz, dr, dphi, dz, R):
+    def __init__(self, nr, nphi, nz, dr, dphi, dz, R, R_in=0.0):
+        """R_in: inner radius of an annular grid, r_i = R_in + (i + 1/2) dr.  The reference's own drivers and its only test
+        pass it (quick_spiral_deposition_gif_v5.py:80, tests/test_spiral_vs_analytic.py:18) to a constructor that does not
+        take it (TypeError at HEAD); here it is accepted and every formula is the reference's with r shifted."""
         self.nr = int(nr); self.nphi = int(nphi); self.nz = int(nz)
         self.dr = float(dr); self.dphi = float(dphi); self.dz = float(dz)
         self.R = float(R)
-        self.r = (np.arange(self.nr, dtype=np.float64) + 0.5) * self.dr
+        self.R_in = float(R_in)
+        self.r = self.R_in + (np.arange(self.nr, dtype=np.float64) + 0.5) * self.dr
         self.r_imh = self.r - 0.5 * self.dr
         self.r_iph = self.r + 0.5 * self.dr
         self.r_outer_face = self.r_iph[-1]
@@ -87,17 +91,17 @@ def _plan(grid, mat, dt, robin_r, zbc):
         raise ValueError("unknown zbc.kind_bot")     # adi3d_cyl_phi_v3.py:283
     if zbc.kind_top not in _lib.ZBC_KINDS:
         raise ValueError("unknown zbc.kind_top")     # :296
-    key = (torch.cuda.current_device(), grid.dr, grid.dphi, grid.dz, mat.rho, mat.cp, mat.k, dt, robin_r.h,
+    key = (torch.cuda.current_device(), grid.dr, grid.dphi, grid.dz, getattr(grid, 'R_in', 0.0), mat.rho, mat.cp, mat.k, dt, robin_r.h,
            robin_r.T_inf, zbc.kind_bot, zbc.kind_top, zbc.h_bot, zbc.h_top, zbc.T_inf_bot, zbc.T_inf_top,
            zbc.T_bot, zbc.T_top)
     pl = grid._plans.get(key)
     if pl is None:
         _device()
         h = ctypes.c_void_p()
-        check(lib.adi_cyl_plan_create(grid.nr, grid.nphi, grid.nz, grid.layout.sx, grid.dr, grid.dphi, grid.dz, mat.rho, mat.cp,
-                                      mat.k, dt, robin_r.h, robin_r.T_inf, _lib.ZBC_KINDS[zbc.kind_bot],
-                                      _lib.ZBC_KINDS[zbc.kind_top], zbc.h_bot, zbc.h_top, zbc.T_inf_bot,
-                                      zbc.T_inf_top, zbc.T_bot, zbc.T_top, ctypes.byref(h)))
+        check(lib.adi_cyl_plan_create_annular(grid.nr, grid.nphi, grid.nz, grid.layout.sx, grid.dr, grid.dphi, grid.dz,
+                                              getattr(grid, 'R_in', 0.0), mat.rho, mat.cp, mat.k, dt, robin_r.h, robin_r.T_inf,
+                                              _lib.ZBC_KINDS[zbc.kind_bot], _lib.ZBC_KINDS[zbc.kind_top], zbc.h_bot,
+                                              zbc.h_top, zbc.T_inf_bot, zbc.T_inf_top, zbc.T_bot, zbc.T_top, ctypes.byref(h)))
         pl = _Plan(h)
         if len(grid._plans) > 16:      # drivers vary dt between segments; keep the cache bounded
             grid._plans.clear()

@@ -534,6 +534,17 @@ int adi_cyl_plan_create(int nr, int nphi, int nz, long plane_stride, double dr, 
                         double h_top, double Tinf_bot, double Tinf_top, double T_bot, double T_top,
                         adi_cyl_plan **out)
 {
+    return adi_cyl_plan_create_annular(nr, nphi, nz, plane_stride, dr, dphi, dz, 0.0, rho, cp, k, dt, robin_h, robin_Tinf, kind_bot,
+                                       kind_top, h_bot, h_top, Tinf_bot, Tinf_top, T_bot, T_top, out);
+}
+
+int adi_cyl_plan_create_annular(int nr, int nphi, int nz, long plane_stride, double dr, double dphi, double dz, double r_in,
+                                double rho, double cp, double k,
+                                double dt, double robin_h, double robin_Tinf, int kind_bot, int kind_top, double h_bot,
+                                double h_top, double Tinf_bot, double Tinf_top, double T_bot, double T_top,
+                                adi_cyl_plan **out)
+{
+    ADI_REQUIRE(r_in >= 0.0, "adi_cyl_plan_create: negative inner radius");
     ADI_REQUIRE(out, "adi_cyl_plan_create: null output");
     ADI_REQUIRE(nr > 0 && nphi > 0 && nz > 0, "adi_cyl_plan_create: bad grid");
     ADI_REQUIRE(kind_bot >= 0 && kind_bot <= 2, "unknown zbc.kind_bot");  // ValueError, adi3d_cyl_phi_v3.py:283
@@ -553,7 +564,7 @@ int adi_cyl_plan_create(int nr, int nphi, int nz, long plane_stride, double dr, 
     // ---- r coefficients: build_coeff_r, adi3d_cyl_phi_v3.py:155-202 -------------------------------
     std::vector<double> ar(nr), br(nr), cr(nr), r_i(nr), r_imh(nr), r_iph(nr);
     for (int i = 0; i < nr; ++i) {
-        const double r = ((double)i + 0.5) * dr;       // GridCyl.r, :38
+        const double r = r_in + ((double)i + 0.5) * dr;       // GridCyl.r, :38 (+ the inner radius of an annular grid)
         r_i[i] = fmax(r, 1e-15);
         r_imh[i] = fmax(r - 0.5 * dr, 1e-15);
         r_iph[i] = r + 0.5 * dr;
@@ -583,7 +594,7 @@ int adi_cyl_plan_create(int nr, int nphi, int nz, long plane_stride, double dr, 
     // ---- phi: fac_i, Sherman-Morrison vectors; phi_solve_spectral, :302-329 ------------------------
     std::vector<double> pf(nr, 0.0), zt((size_t)nr * nphi, 0.0), smden(nr, 1.0);
     for (int i = 1; i < nr; ++i) {
-        const double r = ((double)i + 0.5) * dr;
+        const double r = r_in + ((double)i + 0.5) * dr;
         pf[i] = theta * alpha * dt / (r * r * dphi * dphi);
     }
     if (nphi > 2) {

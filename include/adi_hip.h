@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 8
+#define ADI_ABI_VERSION 9
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -281,6 +281,16 @@ int adi_cyl_plan_create(int nr, int nphi, int nz, long plane_stride, double dr, 
                         int kind_bot, int kind_top, double h_bot, double h_top,
                         double Tinf_bot, double Tinf_top, double T_bot, double T_top,
                         adi_cyl_plan **out);
+/* The same on an annular grid r_i = r_in + (i + 1/2) dr -- the grid quick_spiral_deposition_gif_v5.py:74-80
+ * (build_grid_annular) and tests/test_spiral_vs_analytic.py ask for with GridCyl(..., R_in=R_in); the reference's GridCyl has
+ * no such parameter (TypeError at HEAD).  Every formula is the reference's with r shifted: row 0 keeps the
+ * zero-flux closure of :177-181 (now the inner wall) and its identity phi row (:315-317). */
+int adi_cyl_plan_create_annular(int nr, int nphi, int nz, long plane_stride, double dr, double dphi, double dz,
+                                double r_in, double rho, double cp, double k, double dt,
+                                double robin_h, double robin_Tinf,
+                                int kind_bot, int kind_top, double h_bot, double h_top,
+                                double Tinf_bot, double Tinf_top, double T_bot, double T_top,
+                                adi_cyl_plan **out);
 int adi_cyl_plan_destroy(adi_cyl_plan *plan);
 /* adi_step (BE): T_in is not modified; the four field buffers must be distinct. */
 int adi_cyl_step(const adi_cyl_plan *plan, const double *d_T_in, double *d_T_out,

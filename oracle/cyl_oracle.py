@@ -18,11 +18,15 @@ import numpy as np
 
 
 class GridCyl:  # adi3d_cyl_phi_v3.py:33-43
-    def __init__(self, nr, nphi, nz, dr, dphi, dz, R):
+    def __init__(self, nr, nphi, nz, dr, dphi, dz, R, R_in=0.0):
+        # R_in: the annular grid quick_spiral_deposition_gif_v5.py:80 asks for (the reference's constructor raises TypeError,
+        # SURVEY D1): r shifted by the inner radius, everything else as written.  PARITY UNPINNED for R_in != 0 -- the
+        # reference cannot run it; R_in = 0 is pinned by the golden vectors.
         self.nr = int(nr); self.nphi = int(nphi); self.nz = int(nz)
         self.dr = float(dr); self.dphi = float(dphi); self.dz = float(dz)
         self.R = float(R)
-        self.r = (np.arange(self.nr, dtype=np.float64) + 0.5) * self.dr
+        self.R_in = float(R_in)
+        self.r = self.R_in + (np.arange(self.nr, dtype=np.float64) + 0.5) * self.dr
         self.r_imh = self.r - 0.5 * self.dr
         self.r_iph = self.r + 0.5 * self.dr
         self.r_outer_face = self.r_iph[-1]

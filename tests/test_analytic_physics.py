@@ -148,3 +148,58 @@ def test_perimeter_ratio_correction_improves_the_neumann_case():
     raw = _cylinder_case(hip, 'neumann', nxr, 160, to_state=hip.to_device, to_host=lambda d: d.get())
     cor = _cylinder_case(hip, 'neumann', nxr, 160, to_state=hip.to_device, to_host=lambda d: d.get(), h_scale=gamma)
     assert cor[-1] < 0.2 * raw[-1] and cor[-1] < 5e-3, (raw, cor)
+
+
+# ---- the reference's own (and only) test: spiral deposition on an annular wall against the closed-form series ----------
+# /root/reference/tests/test_spiral_vs_analytic.py:123-209.  It fails at the reference's HEAD with a TypeError
+# (GridCyl(R_in=...)).  tests/golden/make_golden_spiral.py supplies the missing constructor (r shifted by R_in)
+# and runs the reference's own numeric loop and analytic series: golden/cyl_spiral_annulus.npz.  With that the test still
+# fails -- mean |err| 74-145 degrees, max 500-850 against its tolerances 60 / 120 (D10; the series keeps
+# one radial mode per angular order and overshoots the deposition temperature) -- so what is asserted here is what can be:
+#   * the oracle / the HIP backend, driven by the restated deposition loop, reproduce the reference's five fields
+#     (GridCyl(R_in=...) + adi_step_masked with a growing active set): <= 1e-10 relative L-inf, masks identical;
+#   * the restated series (tests/analytic_series.py) reproduces the reference's analytic maps: <= 1e-9;
+#   * numeric vs analytic: the error levels the reference's code produces, as a regression bound (5 % margin).
+def _spiral_case(api, **kw):
+    import analytic_series as an
+    from helpers import golden, rel_linf
+    g = golden('cyl', 'spiral_annulus')
+    k, rho, cp, Tinf, Tdep, R_in, wall, h_side, h_end, z_back, layer_h, n_layers, nphi, tau, nr = g['params']
+    n_layers, nphi, nr = int(n_layers), int(nphi), int(nr)
+    mat = dict(rho=rho, cp=cp, k=k)
+    times = g['times']
+    grid, fields, masks = an.run_spiral_deposition(api, times, mat, Tinf, Tdep, R_in, wall, h_side, h_end, z_back, layer_h,
+                                                   n_layers, tau, nr, nphi, **kw)
+    assert (grid.nr, grid.nphi, grid.nz) == g['fields'].shape[1:] and np.allclose(grid.r, g['r'], rtol=0, atol=1e-15)
+    for i in range(len(times)):
+        assert np.array_equal(masks[i], g['active'][i]), i
+        assert rel_linf(fields[i], g['fields'][i]) <= 1e-10, (i, rel_linf(fields[i], g['fields'][i]))
+    assert fields[-1].max() <= Tdep + 1e-9 and fields[-1].min() >= Tinf - 1e-9          # maximum principle
+    return grid, fields, masks, g
+
+
+def test_spiral_annulus_series_and_oracle_vs_reference():
+    import analytic_series as an
+    from oracle import cyl_oracle as cyl
+    grid, fields, masks, g = _spiral_case(cyl)
+    k, rho, cp, Tinf, Tdep, R_in, wall, h_side, h_end, z_back, layer_h, n_layers, nphi, tau, nr = g['params']
+    ana = an.SpiralAnnulus(dict(rho=rho, cp=cp, k=k), Tinf, Tdep, R_in, wall, h_side, h_side, h_end, z_back, layer_h,
+                           int(n_layers), tau, int(nphi), grid.nz, grid.nphi)
+    ir = int(np.abs(grid.r - (R_in + 0.5 * wall)).argmin())
+    for i, t in enumerate(g['times']):
+        m = ana.map_at(float(t))
+        assert np.array_equal(np.isfinite(m), np.isfinite(g['analytic'][i]))
+        ok = np.isfinite(m)
+        assert np.max(np.abs(m[ok] - g['analytic'][i][ok])) <= 1e-9                     # the restated series = the reference's
+        ok = ok & masks[i][ir].T
+        if ok.any():
+            d = np.abs(fields[i][ir].T - m)[ok]
+            mean_ref, max_ref = g['errors'][i]
+            assert d.mean() <= 1.05 * mean_ref + 1e-9 and d.max() <= 1.05 * max_ref + 1e-9, (t, d.mean(), d.max())
+    assert g['errors'][1:, 0].min() > 60.0          # D10: the reference's own tolerance is out of its own reach
+
+
+@pytest.mark.gpu
+def test_spiral_annulus_on_hip_vs_reference():
+    import adi_thermal_fields_amd.adi3d_hip_cyl as hipcyl
+    _spiral_case(hipcyl)
