@@ -162,9 +162,15 @@ class SelfLoopDistComm(TorchDistComm):
         assert dist.get_world_size(group) == 1
         self.me = dist.get_rank(group)
         self.rank, self.world = rank, world
+        self.bytes_sent = 0
+        self.n_exchanges = 0
 
     def exchange_planes(self, send_lo, send_hi, recv_lo, recv_hi):
         dist, ops = self.dist, []
+        if self.rank > 0:
+            self.bytes_sent += send_hi.numel() * send_hi.element_size()
+        if self.rank < self.world - 1:
+            self.bytes_sent += send_lo.numel() * send_lo.element_size()
         # sends and receives to one peer match in order: what goes up (send_hi) must land in recv_lo, and vice versa
         if self.rank > 0 and self.rank < self.world - 1:
             ops = [dist.P2POp(dist.isend, send_hi, self.me, self.group), dist.P2POp(dist.irecv, recv_lo, self.me, self.group),
@@ -174,10 +180,12 @@ class SelfLoopDistComm(TorchDistComm):
         elif self.rank < self.world - 1:
             ops = [dist.P2POp(dist.isend, send_lo, self.me, self.group), dist.P2POp(dist.irecv, recv_hi, self.me, self.group)]
         if ops:
+            self.n_exchanges += 1
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
 
     def all_gather(self, out, inp):
+        self.bytes_sent += inp.numel() * inp.element_size() * (self.world - 1)
         one = torch.empty_like(inp)
         self.dist.all_gather_into_tensor(one, inp, group=self.group)          # the real collective, world size 1
         out.view(self.world, -1).copy_(one.view(1, -1).expand(self.world, -1))
