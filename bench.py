@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)      # >= 10 warm-up + >= 50 timed steps
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--n', type=int, default=512, help='cells per axis per GPU')
     ap.add_argument('--config', choices=['cart', 'cyl'], default='cart',
                     help="cart: the headline 512^3 Cartesian workload (default); cyl: BASELINE.json configs[3], the "
@@ -150,11 +150,13 @@ def main_cyl(a):
         dist.destroy_process_group()
         return
     N = nr * nphi * nz
-    ms = np.array([[ev[s_][i].elapsed_time(ev[s_][i + 1]) for i in range(3)] for s_ in range(a.steps)]).mean(axis=0)
+    all_ms = np.array([[ev[s_][i].elapsed_time(ev[s_][i + 1]) for i in range(3)] for s_ in range(a.steps)])
+    ms = all_ms.mean(axis=0)
     kernels = {}
     for i, nm in enumerate(st.stage_names):
         gbs = st.stage_bytes_per_cell[i] * N / (ms[i] * 1e-3) / 1e9
-        kernels[nm] = dict(ms=round(float(ms[i]), 4), bytes_per_cell=st.stage_bytes_per_cell[i],
+        kernels[nm] = dict(ms=round(float(ms[i]), 4), ms_median=round(float(np.median(all_ms[:, i])), 4),
+                           ms_min=round(float(all_ms[:, i].min()), 4), bytes_per_cell=st.stage_bytes_per_cell[i],
                            achieved_gbs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
     dom = max(kernels, key=lambda k: kernels[k]['ms'])
     ms_per_step = elapsed / a.steps * 1e3
@@ -308,7 +310,8 @@ def main():
     kernels = {}
     for i, nm in enumerate(stage_names):
         gbs = bytes_per_cell[nm] * N / (mean_ms[i] * 1e-3) / 1e9
-        kernels[nm] = dict(ms=round(float(mean_ms[i]), 4), bytes_per_cell=round(bytes_per_cell[nm], 3),
+        kernels[nm] = dict(ms=round(float(mean_ms[i]), 4), ms_median=round(float(np.median(stage_ms[:, i])), 4),
+                           ms_min=round(float(stage_ms[:, i].min()), 4), bytes_per_cell=round(bytes_per_cell[nm], 3),
                            achieved_gbs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
 
     # what every rank measured, so that the SCALE record shows what RCCL saw: the world size from the process group itself,
