@@ -524,16 +524,42 @@ def _sparse_arg(grid, pack, dense):
     return int(pack.sparse_ok and fresh and not dense) | (2 if getattr(grid, 'all_solid', False) else 0)
 
 
+class _NoFallback:
+    """Bit 2 of `sparse` (include/adi_hip.h): skip the queue reset and the GENERAL launch behind a FAST kernel that is known
+    to take every unit.  Which units a FAST kernel queues depends on the flags, the Dirichlet mask, the variant, the
+    `sparse` bits and the shape -- not on the field -- so the first sweep of a configuration runs without the bit, the
+    number of queued units is read back from the first word of the workspace (one 4-byte copy, once per mask / pack
+    version), and later sweeps of the same configuration carry the bit when that number was zero."""
+
+    def __init__(self, grid, pack, entry, axis, v, sp, work):
+        self.cache = pack.__dict__.setdefault('_nofb', {})
+        self.key = (entry, axis, v, sp, grid.mask_version, getattr(pack, 'mask_version', None), grid.shape, grid.sx,
+                    None if pack.d_dir_mask is None else pack.d_dir_mask.data_ptr())
+        self.work = work
+        self.known = self.cache.get(self.key) if ((sp & 1) and work is not None and work.numel() >= 4) else False
+
+    @property
+    def bit(self):
+        return 4 if self.known else 0
+
+    def learn(self):
+        if self.known is None and not torch.cuda.is_current_stream_capturing():
+            self.cache[self.key] = int(self.work[:4].view(torch.int32)[0].item()) == 0
+
+
 def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None, xlo=None, xhi=None, dense=False):
     _, gam = _gam(grid, mat, params)
     _, work, wb = grid.scratch(2)
     v = pack.variant if variant is None else variant
+    sp = _sparse_arg(grid, pack, dense)
+    nf = _NoFallback(grid, pack, 'sweep', axis, v, sp, work)
     check(lib.adi_sweep(axis, v, _p(t_in), _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
                         _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
-                        _sparse_arg(grid, pack, dense), params.theta,
+                        sp | nf.bit, params.theta,
                         gam, params.dt, float(Tinf), _p(t_out),
                         _p(xlo), _p(xhi),
                         _p(work), wb, _stream()))
+    nf.learn()
 
 
 def fused_supported(grid, cond_pass=False):
@@ -555,10 +581,13 @@ def _explicit_sweep0_into(t, t_out, grid, mat, params, pack, Tinf, variant=None,
     _, work, wb = grid.scratch(2)
     v = pack.variant if variant is None else variant
     vlo, vhi = valid_range(t)
+    sp = _sparse_arg(grid, pack, dense)
+    nf = _NoFallback(grid, pack, 'fused', 0, v, sp, work)
     check(lib.adi_explicit_sweep0(v, _p(t), vlo, vhi, _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
                                   _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
-                                  _sparse_arg(grid, pack, dense), grid.dx, params.dt, kappa, params.theta,
+                                  sp | nf.bit, grid.dx, params.dt, kappa, params.theta,
                                   float(Tinf), _p(t_out), None, None, _p(work), wb, _stream()))
+    nf.learn()
 
 
 def adi_explicit_sweep_axis0(Tn, grid, mat, params, pack, Tinf=0.0, variant=None, dense=False):

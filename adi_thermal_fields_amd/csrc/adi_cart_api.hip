@@ -48,6 +48,7 @@ static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t 
     s.Tinf = Tinf;
     s.sparse = (sparse & 1) ? 1 : 0;
     s.box = (sparse & 2) ? 1 : 0;
+    s.nofb = (sparse & 4) ? 1 : 0;
     hipStream_t st = as_stream(stream);
     SweepArgs a;
     a.in = d_in; a.flags = d_flags; a.coeff = d_coeff;
@@ -150,6 +151,7 @@ static int condense_entry(int axis, int variant, const double *d_in, const uint8
     s.Tinf = Tinf;
     s.sparse = (sparse & 1) ? 1 : 0;
     s.box = (sparse & 2) ? 1 : 0;
+    s.nofb = (sparse & 4) ? 1 : 0;
     hipStream_t st = as_stream(stream);
     SweepArgs a;
     a.in = d_in; a.flags = d_flags; a.coeff = d_coeff;

@@ -60,6 +60,9 @@ struct SweepScal {
                   // (12 more registers fit the 128-VGPR budget: 0.69 instead of 0.80 ms at 512^3)
     int sparse;   // 1: coeff / qflux are non-zero only on cells exposed along the sweep axis (packs built by
                   //    adi_build_coeffs), so they are loaded only there; dir_val only where dir_mask is set
+    int nofb = 0; // promise (bit 2 of `sparse`): the FAST kernel takes every unit of this sweep -- the caller has seen the
+                  //    unit queue of the same (mask, packs, variant, shape) come back empty; the queue reset and the GENERAL
+                  //    launch behind the FAST kernel are skipped (3 + 3 launches of ~4.5 us and their gaps per step)
 };
 
 // cell is in the mask and lacks at least one in-mask neighbour along the sweep axis: the only cells where
@@ -313,6 +316,7 @@ struct Lay {
 // launched right behind it on the same stream, which reads every array of the pack.
 __device__ __forceinline__ void enqueue_unit(unsigned *queue, unsigned unit)
 {
+    if (queue == nullptr) return;          // (no-fallback promise: nobody would drain the queue)
     const unsigned idx = atomicAdd(&queue[0], 1u);
     queue[1 + idx] = unit;
 }

@@ -336,7 +336,9 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
     unsigned *queue = fast ? (unsigned *)work : nullptr;
     unsigned ggrid = grid;
     if (fast) {
-        (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
+        const bool nofb = s.nofb != 0;                 // promise: no unit will be queued (see SweepScal)
+        if (nofb) queue = nullptr;
+        else (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
         const bool vecf = aligned && (n % Mf == 0);
         if (Mf == 16 && M != 16)
             launch_contig_fast<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, vecf, nunits_f, queue, st);
@@ -345,6 +347,7 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
         else
             launch_contig_fast<M, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, vecf, nunits_f, queue, st);
         ggrid = grid < 2048u ? grid : 2048u;
+        if (nofb) return;
     }
     const int ratio = fast ? lwf / lw : 1;
     // coalesced + LDS-transposed access with streaming loads/stores: 1.01 -> 0.92 ms on the dense general-pack sweep at

@@ -306,11 +306,14 @@ static void launch_strided(const StridedPlan &P, const double *in, const uint8_t
 {
     unsigned ggrid = (unsigned)P.ntiles_g;
     if (queue != nullptr) {
-        (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
+        const bool nofb = s.nofb != 0;                 // promise: no tile will be queued (see SweepScal)
+        if (nofb) queue = nullptr;
+        else (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
         if (P.Mf == 32) launch_strided_fast<32, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         else if (P.Mf == 16) launch_strided_fast<16, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         else launch_strided_fast<8, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         ggrid = P.ntiles_g < 1024 ? (unsigned)P.ntiles_g : 1024u;
+        if (nofb) return;
     }
     // every tile whole and within 31-bit byte offsets of its base: the buffer-addressed instantiation (8 / 16 rows per thread)
     const bool whole = !FUSE && M >= 8 && kBufStrided && g.n_inner % P.lines_g == 0 && P.Lpg * M == g.n &&

@@ -145,6 +145,11 @@ int adi_explicit_rhs_planes(const double *d_T, const uint8_t *d_flags, int nx, i
  * except on cells that lack an in-mask neighbour along the axis -- so the kernel loads them only there
  * (and dir_val only where dir_mask is set).  Pass 0 for hand-built packs.  Bit 1 (value 2) is an optional hint: every
  * cell of the box is in the mask (an all-solid box), which lets the strided FAST kernels (fused and unfused) run their leaner build; results do not depend on it.
+ * Bit 2 (value 4) is a PROMISE, not a hint: the FAST kernel takes every unit of this sweep, so the queue reset and the
+ * GENERAL launch behind it are skipped (units the FAST kernel cannot take would be left unwritten).  Which units are queued
+ * depends on the flags, the Dirichlet mask, the variant, `sparse` and the shape only -- never on the field -- so a caller
+ * may set the bit after it has seen the queue of an identical call come back empty: after a sweep without the bit the first
+ * 32-bit word of d_work is the number of queued units (adi3d_hip_coeff.py does exactly that, once per mask / pack version).
  * d_work/work_bytes (adi_sweep_workspace_bytes): c'/d' scratch for lines longer than the in-register limit,
  * otherwise the unit queue that lets a sparse sweep run as a FAST kernel (solid interior) followed by the
  * GENERAL kernel on the queued surface units; with NULL/0 the GENERAL kernel processes everything.

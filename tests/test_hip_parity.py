@@ -595,3 +595,56 @@ def test_structured_masks_fuzz(hip, seed):
     want = run_cart_case(orc, c)['T_final']
     assert rel_linf(got, want) <= TOL, (shape, kind, rel_linf(got, want))
     assert np.array_equal(got[~mask], c['T0'][~mask])
+
+
+def test_no_fallback_promise_is_learnt_per_configuration(hip):
+    """sparse bit 2 (include/adi_hip.h): after a sweep whose unit queue came back empty the host layer skips the queue reset
+    and the GENERAL launch for the same (mask, packs, variant, shape); a configuration that does queue units never gets the
+    bit, and a mask change starts over.  Results are those of the plain path in every case."""
+    from oracle import adi_oracle as orc
+    shape = (256, 16, 32)
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    rng = np.random.default_rng(3)
+    T0 = rng.uniform(20.0, 900.0, shape)
+
+    def run(api, mask, nsteps, grid=None, packs=None):
+        g = grid or api.Grid3D(*shape, dx, mask)
+        mat = api.Material(7800.0, 490.0, 54.0); prm = api.Params(80.0 * dx * dx / alpha, 0.5)
+        pk = packs or api.precompute_coeff_packs_unified(g, mat, robin_h=300.0)
+        T = np.array(T0)
+        step = getattr(api, 'adi_step_hip_coeff', None) or api.adi_step_numba_coeff
+        for _ in range(nsteps):
+            T = step(T, g, mat, prm, pk, Tinf=20.0)
+        return T, g, pk
+
+    solid = np.ones(shape, bool)
+    got, g, pk = run(hip, solid, 3)
+    want, _, _ = run(orc, solid, 3)
+    assert rel_linf(got, want) <= TOL
+    learnt = [v for p in pk for v in p._nofb.values()]
+    assert learnt and all(learnt)                                   # the all-solid box queues nothing: every sweep carries the bit
+    # a Dirichlet plane queues units: never promised, still right
+    dm = np.zeros(shape, bool); dm[:, 0, :] = True
+    res = []
+    for api in (hip, orc):
+        gg = api.Grid3D(*shape, dx, solid)
+        mat = api.Material(7800.0, 490.0, 54.0); prm = api.Params(80.0 * dx * dx / alpha, 0.5)
+        pp = api.precompute_coeff_packs_unified(gg, mat, robin_h=300.0, dir_mask=dm, dir_value=55.0)
+        T = np.array(T0)
+        step = getattr(api, 'adi_step_hip_coeff', None) or api.adi_step_numba_coeff
+        for _ in range(3):
+            T = step(T, gg, mat, prm, pp, Tinf=20.0)
+        res.append(T)
+        if api is hip:
+            assert not all(v for p in pp for v in p._nofb.values())
+    assert rel_linf(res[0], res[1]) <= TOL
+    # the mask changes under the same Grid3D: new version, nothing promised until seen again
+    holes = rng.random(shape) > 0.1
+    g.mask = holes
+    mat = hip.Material(7800.0, 490.0, 54.0)
+    pk2 = hip.precompute_coeff_packs_unified(g, mat, robin_h=300.0)
+    got2, _, _ = run(hip, holes, 3, grid=g, packs=pk2)
+    want2, _, _ = run(orc, holes, 3)
+    assert rel_linf(got2, want2) <= TOL
+    assert not all(v for p in pk2 for v in p._nofb.values())
