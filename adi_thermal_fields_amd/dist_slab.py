@@ -201,6 +201,8 @@ class HipEngine:
         self.hip, self._lib, self.lib, self.check = hip, _lib, _lib.lib, _lib.check
         self.device = hip._device()
         self.box_hint = 0          # 2: every cell of every slab is in the mask (SlabStepper.set_mask decides, collectively)
+        self.mask_epoch = 0        # bumped by SlabStepper.set_mask: the flags / packs are rebuilt in place
+        self._nofb = {}            # no-fallback promise per sweep configuration (bit 2 of `sparse`, include/adi_hip.h)
 
     def layout(self, nx, ny, nz, sx=None):
         return self.hip.Layout(nx, ny, nz, sx)
@@ -245,11 +247,25 @@ class HipEngine:
             self._work = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._work
 
+    def _promise(self, entry, axis, variant, Li, flags, pack):
+        """(key, bit): which units the FAST kernels queue depends on the flags, the Dirichlet mask, the variant and the shape
+        only; a configuration seen to queue nothing skips the queue reset and the GENERAL launch from then on"""
+        key = (entry, axis, variant, Li.nx, Li.ny, Li.nz, Li.sx, flags.data_ptr(), pack[0].data_ptr(),
+               None if pack[1] is None else pack[1].data_ptr(), self.box_hint, self.mask_epoch)
+        return key, (4 if self._nofb.get(key) else 0)
+
+    def _learn(self, key, w):
+        if key not in self._nofb and not torch.cuda.is_current_stream_capturing():
+            self._nofb[key] = int(w[:4].view(torch.int32)[0].item()) == 0
+
     def sweep(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, xlo=None, xhi=None):
         h = self.hip
         w = self._workspace(Li)
-        self.check(self.lib.adi_sweep(*self._args(axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf),
-                                      h._p(t_out), h._p(xlo), h._p(xhi), h._p(w), w.numel(), h._stream()))
+        key, bit = self._promise('sweep', axis, variant, Li, flags, pack)
+        a = list(self._args(axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf))
+        a[12] |= bit
+        self.check(self.lib.adi_sweep(*a, h._p(t_out), h._p(xlo), h._p(xhi), h._p(w), w.numel(), h._stream()))
+        self._learn(key, w)
 
     def condense(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, cond):
         h = self.hip
@@ -389,6 +405,9 @@ class SlabStepper:
         halo planes, rebuilds the neighbour flags and the coefficient packs on the extended slab."""
         E, L = self.engine, self.Lext
         self._mask_version += 1
+        if hasattr(E, 'mask_epoch'):
+            E.mask_epoch += 1                      # what the engine learnt about empty unit queues belongs to the old mask
+            E._nofb.clear()
         m_ext = np.zeros((self.nxl + 2, self.ny, self.nz), dtype=np.bool_)
         m_ext[1:-1] = mask_local
         d_mask = L.to_layout(m_ext, torch.uint8)
