@@ -1,5 +1,5 @@
 """explicit + axis-0 sweep as two kernels vs the fused kernel (adi_explicit_sweep0) at n^3, lean Robin workload.
-    [ADI_FUSE_KG=k] python scripts/fused_probe.py [n]"""
+    python scripts/fused_probe.py [n]"""
 import os
 import sys
 
@@ -46,5 +46,5 @@ def timeit(fn, reps=20):
 
 
 t2 = timeit(two); t1 = timeit(one)
-print('KG=%s n=%d: two kernels %.4f ms, fused %.4f ms (%.0f GB/s on 17 B/cell), identical=%s maxdiff=%.3e' % (
-    os.environ.get('ADI_FUSE_KG', 'default'), n, t2, t1, 17.03 * n ** 3 / t1 / 1e6, bool(torch.equal(B, C)), float((B - C).abs().max())), flush=True)
+print('n=%d: two kernels %.4f ms, fused %.4f ms (%.0f GB/s on 17 B/cell), identical=%s maxdiff=%.3e' % (
+    n, t2, t1, 17.03 * n ** 3 / t1 / 1e6, bool(torch.equal(B, C)), float((B - C).abs().max())), flush=True)
