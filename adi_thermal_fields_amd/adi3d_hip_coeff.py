@@ -529,22 +529,30 @@ class _NoFallback:
     to take every unit.  Which units a FAST kernel queues depends on the flags, the Dirichlet mask, the variant, the
     `sparse` bits and the shape -- not on the field -- so the first sweep of a configuration runs without the bit, the
     number of queued units is read back from the first word of the workspace (one 4-byte copy, once per mask / pack
-    version), and later sweeps of the same configuration carry the bit when that number was zero."""
+    version), and later sweeps of the same configuration carry the bit when that number was zero.  The read-back is a
+    host synchronisation, so it waits for the third sweep of a configuration: a layer-birth loop that changes the mask every
+    two or three steps (waam.run_layer_birth) never pays it."""
+    LEARN_AFTER = 3
 
     def __init__(self, grid, pack, entry, axis, v, sp, work):
         self.cache = pack.__dict__.setdefault('_nofb', {})
         self.key = (entry, axis, v, sp, grid.mask_version, getattr(pack, 'mask_version', None), grid.shape, grid.sx,
                     None if pack.d_dir_mask is None else pack.d_dir_mask.data_ptr())
         self.work = work
-        self.known = self.cache.get(self.key) if ((sp & 1) and work is not None and work.numel() >= 4) else False
+        self.state = self.cache.get(self.key, 0) if ((sp & 1) and work is not None and work.numel() >= 4) else False
 
     @property
     def bit(self):
-        return 4 if self.known else 0
+        return 4 if self.state is True else 0
 
     def learn(self):
-        if self.known is None and not torch.cuda.is_current_stream_capturing():
-            self.cache[self.key] = int(self.work[:4].view(torch.int32)[0].item()) == 0
+        st = self.state
+        if st is True or st is False:
+            return
+        st += 1                                   # uses of this configuration so far
+        if st >= self.LEARN_AFTER and not torch.cuda.is_current_stream_capturing():
+            st = int(self.work[:4].view(torch.int32)[0].item()) == 0
+        self.cache[self.key] = st
 
 
 def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None, xlo=None, xhi=None, dense=False):
@@ -821,7 +829,8 @@ class StagedStepper:
         X.copy_(g.layout.to_layout(T, torch.float64))
         if graph and nsteps >= 2 and st['g'] is None:
             g.scratch(2)                                   # every buffer exists before the capture
-            self._step_into(X, Y); self._step_into(Y, X)   # warm-up outside the capture (lazy module loads); harmless:
+            self._step_into(X, Y); self._step_into(Y, X)   # warm-up outside the capture (lazy module loads, and the
+            self._step_into(X, Y); self._step_into(Y, X)   # no-fallback promise is learnt on the third step); harmless:
             X.copy_(g.layout.to_layout(T, torch.float64))  # X is restored
             torch.cuda.synchronize()
             cg = torch.cuda.CUDAGraph()

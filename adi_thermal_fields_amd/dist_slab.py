@@ -252,11 +252,16 @@ class HipEngine:
         only; a configuration seen to queue nothing skips the queue reset and the GENERAL launch from then on"""
         key = (entry, axis, variant, Li.nx, Li.ny, Li.nz, Li.sx, flags.data_ptr(), pack[0].data_ptr(),
                None if pack[1] is None else pack[1].data_ptr(), self.box_hint, self.mask_epoch)
-        return key, (4 if self._nofb.get(key) else 0)
+        return key, (4 if self._nofb.get(key) is True else 0)
 
     def _learn(self, key, w):
-        if key not in self._nofb and not torch.cuda.is_current_stream_capturing():
-            self._nofb[key] = int(w[:4].view(torch.int32)[0].item()) == 0
+        st = self._nofb.get(key, 0)
+        if st is True or st is False:
+            return
+        st += 1                    # the read-back synchronises the host: wait for the third sweep of a configuration
+        if st >= 3 and not torch.cuda.is_current_stream_capturing():
+            st = int(w[:4].view(torch.int32)[0].item()) == 0
+        self._nofb[key] = st
 
     def sweep(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, xlo=None, xhi=None):
         h = self.hip

@@ -623,7 +623,7 @@ def test_no_fallback_promise_is_learnt_per_configuration(hip):
     want, _, _ = run(orc, solid, 3)
     assert rel_linf(got, want) <= TOL
     learnt = [v for p in pk for v in p._nofb.values()]
-    assert learnt and all(learnt)                                   # the all-solid box queues nothing: every sweep carries the bit
+    assert learnt and all(v is True for v in learnt)               # the all-solid box queues nothing: every sweep carries the bit
     # a Dirichlet plane queues units: never promised, still right
     dm = np.zeros(shape, bool); dm[:, 0, :] = True
     res = []
@@ -637,7 +637,7 @@ def test_no_fallback_promise_is_learnt_per_configuration(hip):
             T = step(T, gg, mat, prm, pp, Tinf=20.0)
         res.append(T)
         if api is hip:
-            assert not all(v for p in pp for v in p._nofb.values())
+            assert not all(v is True for p in pp for v in p._nofb.values())
     assert rel_linf(res[0], res[1]) <= TOL
     # the mask changes under the same Grid3D: new version, nothing promised until seen again
     holes = rng.random(shape) > 0.1
@@ -647,4 +647,4 @@ def test_no_fallback_promise_is_learnt_per_configuration(hip):
     got2, _, _ = run(hip, holes, 3, grid=g, packs=pk2)
     want2, _, _ = run(orc, holes, 3)
     assert rel_linf(got2, want2) <= TOL
-    assert not all(v for p in pk2 for v in p._nofb.values())
+    assert not all(v is True for p in pk2 for v in p._nofb.values())
