@@ -59,9 +59,10 @@ inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok,
         // 32-line tiles with n/16 rows per thread: only where the kernel keeps few arrays alive (pass A); the solve
         // kernel needs > 200 VGPRs at 32 rows per thread and runs faster on 16-line tiles with 16 rows
         if (wide_ok && n % 16 == 0 && (n / 16 == 8 || n / 16 == 16 || n / 16 == 32)) { mf = n / 16; lf = 32; }   // Lpf = 16
-        else if (n > 512 && n % 32 == 0 && n / 32 <= 32 && !fused && g.stride <= 131072) {
+        else if (n >= 512 && n % 32 == 0 && n / 32 <= 32 && !fused && g.stride <= 131072) {
             // long lines, rows less than 1 MiB apart: 32 rows per thread keep 16-line tiles in 512 threads (1024 x 128 x 256:
-            // 112 -> 182 Gcell/s); with 2 MiB planes the 8-line tiles of 16 rows are the faster ones (233 vs 212)
+            // 112 -> 182 Gcell/s); with 2 MiB planes the 8-line tiles of 16 rows are the faster ones (233 vs 212).  From
+            // n = 512 (16 segments: 256-thread workgroups, four per CU instead of two): axis 1 of 512^3 0.424 -> 0.414 ms
             mf = 32; lf = 16;
         } else {
             const int m2 = (n > 256) ? 16 : 8;
