@@ -58,7 +58,14 @@ inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok,
         int mf = 0, lf = 0;
         // 32-line tiles with n/16 rows per thread: only where the kernel keeps few arrays alive (pass A); the solve
         // kernel needs > 200 VGPRs at 32 rows per thread and runs faster on 16-line tiles with 16 rows
-        if (wide_ok && n % 16 == 0 && (n / 16 == 8 || n / 16 == 16 || n / 16 == 32)) { mf = n / 16; lf = 32; }   // Lpf = 16
+        // exact fits first: 20 / 24 / 28 rows per thread where they cut the line into exactly 16 or 32 segments (n = 320, 384,
+        // 448, 640, 768, 896) -- with 16 or 32 rows those lines fill 20 - 28 of 32 segment slots of every workgroup
+        int exact = 0;
+        if (!fused && !wide_ok && n >= 320 && !(n % 16 == 0 && ((n / 16) & (n / 16 - 1)) == 0))
+            for (int m = 20; m <= 28 && !exact; m += 4)
+                if (n % m == 0 && (n / m == 16 || n / m == 32)) exact = m;
+        if (exact) { mf = exact; lf = 16; }
+        else if (wide_ok && n % 16 == 0 && (n / 16 == 8 || n / 16 == 16 || n / 16 == 32)) { mf = n / 16; lf = 32; }   // Lpf = 16
         else if (n >= 512 && n % 32 == 0 && n / 32 <= 32 && !fused && g.stride <= 131072) {
             // long lines, rows less than 1 MiB apart: 32 rows per thread keep 16-line tiles in 512 threads (1024 x 128 x 256:
             // 112 -> 182 Gcell/s); with 2 MiB planes the 8-line tiles of 16 rows are the faster ones (233 vs 212).  From

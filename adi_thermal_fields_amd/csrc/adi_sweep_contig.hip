@@ -1,71 +1,9 @@
 // adi_sweep_contig.hip -- K3: the batched tridiagonal sweep along the contiguous axis (memory axis 2; BASELINE.json's
 // "x-sweep"): sweep_axis2 + thomas_solve of adi3d_numba_coeff.py:205-237, :121-130 in the full-length identity-row form
 // of adi3d_gpu_coeff.py:154-191.  Hand-written HIP for gfx950; HBM-bound, no MFMA.
-#include "adi_cart_host.hpp"
+#include "adi_contig_dev.hpp"
 
 namespace adi {
-
-// ------------------------------------------------------------------------------------------------
-// K3: contiguous-axis sweep.  One wave solves 64/Lp lines; lane li of a line owns rows
-// [li*M, li*M+M) in registers.  No LDS, no barriers: waves are fully independent, so a CU holds
-// many lines in different phases and HBM requests never drain.
-// VEC: n % M == 0 and M even -> every lane's chunk is whole and 16-byte aligned (dwordx4 accesses).
-// ------------------------------------------------------------------------------------------------
-template <int M, bool VEC>
-__device__ __forceinline__ void load_rows_contig(const double *__restrict__ p, long base, int r0, int n,
-                                                 bool active, double (&v)[M])
-{
-    if (VEC) {
-        if (active && r0 < n) {
-            const double2 *q = reinterpret_cast<const double2 *>(p + base);
-#pragma unroll
-            for (int i = 0; i < M / 2; ++i) {
-                const double2 t = q[i];      // lane-owned chunks: several instructions share a 128-byte line -> default policy (nt: 1.01 -> 1.60 ms)
-                v[2 * i] = t.x;
-                v[2 * i + 1] = t.y;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < M; ++r) v[r] = 0.0;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < M; ++r) v[r] = (active && r0 + r < n) ? p[base + r] : 0.0;
-    }
-}
-
-// M flag/mask bytes of a lane's chunk, one byte per row in `b[r]`
-template <int M, bool VEC>
-__device__ __forceinline__ void load_bytes_contig(const uint8_t *__restrict__ p, long base, int r0, int n,
-                                                  bool active, unsigned (&b)[M])
-{
-#pragma unroll
-    for (int r = 0; r < M; ++r) b[r] = 0;
-    if (VEC) {
-        if (active && r0 < n) {
-            if (M == 2) {
-                const unsigned w = *reinterpret_cast<const uint16_t *>(p + base);
-                b[0] = w & 0xffu;
-                b[1] = w >> 8;
-            } else if (M == 4) {
-                const unsigned w = *reinterpret_cast<const uint32_t *>(p + base);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] = (w >> (8 * r)) & 0xffu;
-            } else {
-#pragma unroll
-                for (int h = 0; h < M / 8; ++h) {
-                    const uint64_t w = *reinterpret_cast<const uint64_t *>(p + base + 8 * h);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) b[8 * h + r] = (unsigned)((w >> (8 * r)) & 0xffull);
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < M; ++r)
-            if (active && r0 + r < n) b[r] = p[base + r];
-    }
-}
 
 // GENERAL body for one wave-unit (unit = index of a group of 64/Lp consecutive lines)
 template <int M, bool VEC, bool HAS_DIR, bool HAS_Q, bool COAL>
@@ -170,145 +108,11 @@ __global__ __launch_bounds__(256) void k_sweep_contig(
     }
 }
 
-// FAST kernel (sparse packs only): waves whose lanes all hold uniform-interior segments (rows 1..M-2 have both
-// z-neighbours in the mask and are not Dirichlet; row 0 may start a line / carry a Robin coefficient; the
-// separator row is general).  Such a wave needs no reciprocal chains (condense_uniform) and ~50 VGPRs, so
-// 8 waves per SIMD keep HBM busy.  Other waves are queued for the GENERAL kernel.
-template <int M, int MODE, bool HAS_DIR, bool HAS_Q>
-__global__ __launch_bounds__(256) void k_sweep_contig_fast(
-    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
-    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    double *__restrict__ out, Lay L, int Lp, SweepScal s, long nunits, unsigned *__restrict__ queue, UniC<M> U)
-{
-    const int n = L.nz;
-    const long nlines = (long)L.nx * L.ny;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + wave));
-    if (unit >= nunits) return;
-    const int lw = 64 >> (__ffs(Lp) - 1);
-    const int li = lane & (Lp - 1);
-    const unsigned line = (unsigned)unit * (unsigned)lw + ((unsigned)lane >> (__ffs(Lp) - 1));   // < 2^31 lines
-    const bool active = line < (unsigned long)nlines;
-    const int r0 = li * M;
-    const unsigned pi = line / (unsigned)L.ny;
-    const long base = (long)pi * L.sx + (long)(line - pi * (unsigned)L.ny) * n + r0;
-
-    constexpr bool VEC = MODE != 0;
-    __shared__ __align__(16) double strips[MODE == 2 ? 4 * 32 * (M + 2) : 2];
-    double *strip = strips + (MODE == 2 ? wave * 32 * (M + 2) : 0);
-    // MODE 2: the 64/Lp lines of a unit are consecutive in memory (host checks ny % lw == 0), so the wave's 64*M
-    // doubles start at the base of lane 0
-    const long wbase = __shfl(base, 0);
-    double d[M];
-    unsigned fb[M], db[M];
-    load_bytes_contig<M, VEC>(flags, base, r0, n, active, fb);
-    if (HAS_DIR) load_bytes_contig<M, VEC>(dmask, base, r0, n, active, db);
-    if constexpr (MODE == 2) coal_load<M>(in + wbase, strip, lane, d);
-    else load_rows_contig<M, VEC>(in, base, r0, n, active, d);
-    // the two ends of a line are always exposed: fetch their coefficient / flux with the first batch of loads
-    const bool sp0 = active && li == 0, spS = active && (r0 + M == n);
-    const double co0s = sp0 ? coeff[base] : 0.0, coSs = spS ? coeff[base + M - 1] : 0.0;
-    double q0s = 0.0, qSs = 0.0;
-    if (HAS_Q) { q0s = sp0 ? qf[base] : 0.0; qSs = spS ? qf[base + M - 1] : 0.0; }
-    // padding lanes (beyond the end of a line whose segment count is not a power of two, or beyond the last line)
-    // own no rows: they never force the unit to the GENERAL kernel, export an identity block and store nothing
-    const bool pad = !active || r0 >= n;
-    int kind = SEG_NONE, Lm = 0;                    // segment class of this lane (classify_mixed) and length of a mixed run
-    {
-        const unsigned FULL = 1u | (3u << 5), ROW0 = 1u | (1u << 6);
-        bool uni = ((fb[0] & ROW0) == ROW0) && !(HAS_DIR && db[0] != 0), nodir = !(HAS_DIR && db[0] != 0);
-        unsigned inm = fb[0] & 1u;
-#pragma unroll
-        for (int r = 1; r < M - 1; ++r) {
-            uni = uni && ((fb[r] & FULL) == FULL) && !(HAS_DIR && db[r] != 0);
-            nodir = nodir && !(HAS_DIR && db[r] != 0);
-        }
-#pragma unroll
-        for (int r = 1; r < M; ++r) inm |= (fb[r] & 1u) << r;
-        if (pad) kind = SEG_PAD;
-        else if (uni) kind = SEG_UNI;
-        else {
-            kind = classify_mixed<M>(inm, fb[0], 5, Lm);
-            if (kind >= SEG_TAIL && !nodir) kind = SEG_NONE;
-        }
-    }
-    const bool off = kind == SEG_OFF;
-    if (!__all(kind != SEG_NONE)) {
-        if (lane == 0) enqueue_unit(queue, (unsigned)unit);
-        return;
-    }
-    // row 0 and the separator row are general rows; only they can carry a coefficient / flux / Dirichlet value
-    const bool e0 = axis_exposed(fb[0], 5), eS = axis_exposed(fb[M - 1], 5);
-    const double co0 = e0 ? (sp0 ? co0s : coeff[base]) : 0.0, coS = eS ? (spS ? coSs : coeff[base + M - 1]) : 0.0;
-    double q0 = 0.0, qS = 0.0, dvS = 0.0;
-    if (HAS_Q) { q0 = e0 ? (sp0 ? q0s : qf[base]) : 0.0; qS = eS ? (spS ? qSs : qf[base + M - 1]) : 0.0; }
-    const bool dirS = HAS_DIR && db[M - 1] != 0;
-    if (HAS_DIR) dvS = dirS ? dval[base + M - 1] : 0.0;
-    double a0, b0, c0, aS, bS, cS;
-    assemble_row<HAS_DIR, HAS_Q>(fb[0] & 1u, (fb[0] >> 5) & 1u, (fb[0] >> 6) & 1u, false, d[0], co0, 0.0, q0, s, a0,
-                                 b0, c0, d[0]);
-    assemble_row<HAS_DIR, HAS_Q>(fb[M - 1] & 1u, (fb[M - 1] >> 5) & 1u, (fb[M - 1] >> 6) & 1u, dirS, d[M - 1], coS,
-                                 dvS, qS, s, aS, bS, cS, d[M - 1]);
-    Cond k;
-    double kappa;
-    condense_uniform<M>(U, a0, b0, d, k, kappa);
-    if (pad || off) {                               // identity block; an off segment keeps d = in, which it stores back
-        k.gF = k.aF = k.cF = k.gL = k.aL = k.cL = 0.0;
-        kappa = 0.0; aS = 0.0; bS = 1.0; cS = 0.0;
-        if (pad) d[M - 1] = 0.0;
-    }
-    double2 bmod = make_double2(1.0, 1.0);
-    if (kind >= SEG_TAIL) mixed_lane_condense<M, HAS_Q>(kind, Lm, U, s, coeff + base, qf + base, 1L, a0, b0, d, bmod, k);
-    const double gFn = __shfl_down(k.gF, 1, Lp), aFn = __shfl_down(k.aF, 1, Lp), cFn = __shfl_down(k.cF, 1, Lp);
-    double ra, rb, rc, rd;
-    reduced_row(aS, bS, cS, d[M - 1], k, gFn, aFn, cFn, ra, rb, rc, rd);
-    const double xS = pcr_solve(ra, rb, rc, rd, li, Lp);
-    double xL = __shfl_up(xS, 1, Lp);
-    if (li == 0) xL = 0.0;
-    if (kind == SEG_UNI || kind == SEG_PAD) back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
-    else if (kind >= SEG_TAIL) mixed_lane_back_solve<M>(kind, Lm, U, bmod, a0, d, xL, xS);
-    if constexpr (MODE == 2) {
-        coal_store<M>(out + wbase, strip, lane, d);      // (the host takes this mode only when no lane is padding)
-    } else if (pad) {
-        // nothing to store
-    } else if (VEC) {
-        double2 *q = reinterpret_cast<double2 *>(out + base);
-#pragma unroll
-        for (int i = 0; i < M / 2; ++i) q[i] = make_double2(d[2 * i], d[2 * i + 1]);   // lane-owned chunks: default policy
-    } else {
-#pragma unroll
-        for (int r = 0; r < M; ++r) out[base + r] = d[r];
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // host-side launch logic
 // ------------------------------------------------------------------------------------------------
 static int contig_rows_per_lane(int n) { return n <= 128 ? 2 : (n <= 256 ? 4 : (n <= 512 ? 8 : 16)); }
 
-template <int MF, bool HAS_DIR, bool HAS_Q>
-static void launch_contig_fast(const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
-                               const double *dval, const double *qf, double *out, const Lay &L, SweepScal s, bool vec,
-                               long nunits_f, unsigned *queue, hipStream_t st)
-{
-    const int Lpf = next_pow2(L.nz / MF);
-    const unsigned grid = (unsigned)((nunits_f + 3) / 4);
-    const UniC<MF> U = make_unic<MF>(s.tg);
-    const int lwf = 64 / Lpf;
-    // coalesced + LDS-transposed access: whole units of contiguous lines (full last unit, no plane straddling)
-    const bool coal = vec && MF >= 4 && Lpf * MF == L.nz && (L.ny % lwf == 0) &&
-                      (((long)L.nx * L.ny) % lwf == 0);
-    if (coal)
-        hipLaunchKernelGGL((k_sweep_contig_fast<(MF >= 4 ? MF : 4), 2, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
-                           dmask, dval, qf, out, L, Lpf, s, nunits_f, queue, make_unic<(MF >= 4 ? MF : 4)>(s.tg));
-    else if (vec)
-        hipLaunchKernelGGL((k_sweep_contig_fast<MF, 1, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
-                           dmask, dval, qf, out, L, Lpf, s, nunits_f, queue, U);
-    else
-        hipLaunchKernelGGL((k_sweep_contig_fast<MF, 0, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags,
-                           coeff, dmask, dval, qf, out, L, Lpf, s, nunits_f, queue, U);
-}
 
 template <int M, bool HAS_DIR, bool HAS_Q>
 static void launch_contig(const double *in, const uint8_t *flags, const double *coeff, const uint8_t *dmask,
@@ -327,8 +131,17 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
     // FAST kernel: as many rows per lane as divide the line (16, else 8), so that one in-wave PCR serves several lines --
     // n = 512: two lines per wave, n = 256: four (with the GENERAL kernel's 4 rows per lane the PCR ran over 64 lanes per
     // line: 155 Gcell/s at 256^3 against 311 at nz = 512)
+    // Segment counts that are not a power of two leave lanes of the in-wave PCR idle (n = 320: 20 segments of 16 rows in 32
+    // lanes, 37 % of every wave padding; 209 against 270 Gcell/s at nz = 256).  Where 20, 24 or 28 rows per lane cut the
+    // line into exactly 16, 32 or 64 segments the FAST kernel takes that many (n = 320, 384, 448, 640, 768, 896, 1280, ...)
     int Mf = M;
-    if (n >= 128 && n % 16 == 0 && n / 16 <= 64) Mf = 16;
+    const auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    int exact = 0;
+    if (n >= 256 && !(n % 16 == 0 && pow2(n / 16)))
+        for (int m = 20; m <= 28 && !exact; m += 4)
+            if (n % m == 0 && pow2(n / m) && n / m >= 8 && n / m <= 64) exact = m;
+    if (exact) Mf = exact;
+    else if (n >= 128 && n % 16 == 0 && n / 16 <= 64) Mf = 16;
     else if (n >= 64 && n % 8 == 0 && n / 8 <= 64 && M < 8) Mf = 8;
     const int lwf = 64 / next_pow2((n + Mf - 1) / Mf);
     const long nunits_f = (nlines + lwf - 1) / lwf;
@@ -340,7 +153,9 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
         if (nofb) queue = nullptr;
         else (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
         const bool vecf = aligned && (n % Mf == 0);
-        if (Mf == 16 && M != 16)
+        if (Mf > 16)          // 20 / 24 / 28 rows per lane: instantiated in adi_sweep_contig_x.hip
+            contig_fast_exact(Mf, HAS_DIR, HAS_Q, in, flags, coeff, dmask, dval, qf, out, L, s, vecf, nunits_f, queue, st);
+        else if (Mf == 16 && M != 16)
             launch_contig_fast<16, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, vecf, nunits_f, queue, st);
         else if (Mf == 8 && M != 8)
             launch_contig_fast<8, HAS_DIR, HAS_Q>(in, flags, coeff, dmask, dval, qf, out, L, s, vecf, nunits_f, queue, st);

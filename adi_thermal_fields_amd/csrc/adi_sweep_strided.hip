@@ -2,8 +2,7 @@
 // + thomas_solve of adi3d_numba_coeff.py:133-202, :121-130 (identity-row form of adi3d_gpu_coeff.py:154-191), the form
 // with the explicit stage (lap1D_x/y/z + R0, :240-298) folded into the loads of the axis-0 sweep, and K4, the
 // thread-per-line sweep for lines beyond 1024 rows.  Hand-written HIP for gfx950; HBM-bound, no MFMA.
-#include "adi_cart_host.hpp"
-#include "adi_strided_dev.hpp"
+#include "adi_strided_fast.hpp"
 
 namespace adi {
 
@@ -133,111 +132,6 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
     }
 }
 
-template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false, bool MIXED = true>
-__global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_fast(
-    const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
-    const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
-    double *__restrict__ out, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,
-    const double *__restrict__ xlo, const double *__restrict__ xhi, SweepScal s, unsigned *__restrict__ queue,
-    UniC<M> U, Fuse fz)
-{
-    extern __shared__ __align__(16) double sm[];
-    const int tid = threadIdx.x;
-    long tile = xcd_chunk_tile(blockIdx.x, ntiles);
-    if (FUSE && fz.kg > 0) tile = tile_jfast(tile, fz);
-    const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
-    const int ti = (int)(tile - to * tiles_inner);
-    const int kk = tid & (LINES - 1), sg = tid >> (__ffs(LINES) - 1);   // LINES is a power of two
-    const int kcol = ti * LINES + kk;
-    const bool active = kcol < g.n_inner;
-    const long base = to * g.outer_stride + kcol;
-    const int r0 = sg * M;
-    const long line_id = to * (long)g.n_inner + kcol;
-
-    double d[M];
-    unsigned f0, fS;
-    bool dirS;
-    // block-uniform tile base (scalar) + one 32-bit per-thread offset for every row of every array
-    const long tbase = to * g.outer_stride + (long)ti * LINES;
-    const unsigned voff = (unsigned)((long)r0 * g.stride + kk);
-    const bool pad = r0 >= g.n;                    // this thread's segment lies beyond the end of the line
-    int kind = SEG_NONE, Lm = 0;                   // segment class (classify_mixed) and length of a mixed run
-    bool lane_fast;
-    // flag bytes through packed 16-byte loads (load_bytes_packed16): 16-line tiles whose byte rows are 16-byte aligned
-    uint8_t *strip = nullptr;
-    if (M % 4 == 0 && M <= 16 && LINES == 16 && (g.stride & 15) == 0 && (tbase & 15) == 0 && ((uintptr_t)flags & 15) == 0)
-        strip = reinterpret_cast<uint8_t *>(sm + 7 * LINES * (Lp + 1)) + (size_t)sg * (LINES * M);
-    if constexpr (FUSE) {
-        // whole tiles only (block-uniform): anything else goes to the GENERAL kernel before a single load is issued
-        if (LINES != 16 || (ti + 1) * LINES > g.n_inner || g.n % M != 0) {
-            if (tid == 0) enqueue_unit(queue, (unsigned)tile);
-            return;
-        }
-        // a padding segment (line with fewer than Lp segments) re-reads segment 0 -- valid addresses, values unused
-        const int r0e = pad ? 0 : r0;
-        lane_fast = fast_segment_load_fused<M, HAS_DIR, MIXED>(in, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g,
-                                                               pad ? (unsigned)kk : voff, r0e, kk, tbase, fz, d, f0, fS, dirS,
-                                                               kind, Lm, strip) || pad;
-        if (pad) kind = SEG_PAD;
-    } else {
-        // whole tiles whose rows fit 31-bit byte offsets take the buffer-addressed loader (block-uniform choice)
-        const bool whole = kBufStrided && (ti + 1) * LINES <= g.n_inner && Lp * M == g.n &&
-                           (long)g.n * g.stride * 8 < 0x7fffffffL;
-        if (whole)
-            lane_fast = fast_segment_load_buf<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, d,
-                                                          f0, fS, dirS, kind, Lm, strip);
-        else
-            lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
-                                                      active, d, f0, fS, dirS, kind, Lm);
-    }
-    if (pad) { f0 = 0; fS = 0; dirS = false; }       // (the fused loader showed a padding thread segment 0's flags)
-    if (!MIXED && kind >= SEG_TAIL) lane_fast = false;
-    if (!__syncthreads_and(lane_fast)) {
-        if (tid == 0) enqueue_unit(queue, (unsigned)tile);
-        return;
-    }
-    double a0, b0, aS, bS, cS;
-    fast_segment_ends<M, HAS_DIR, HAS_Q>(coeff, dval, qf, g, base, r0, f0, fS, dirS, s, d, a0, b0, aS, bS, cS);
-    if (r0 == 0) {
-        if (xlo != nullptr) d[0] = __builtin_fma(-a0, xlo[line_id], d[0]);
-        a0 = 0.0;
-    }
-    if (r0 + M == g.n) {
-        if (xhi != nullptr) d[M - 1] = __builtin_fma(-cS, xhi[line_id], d[M - 1]);
-        cS = 0.0;
-    }
-    Cond k;
-    double kappa;
-    condense_uniform<M>(U, a0, b0, d, k, kappa);
-    const bool off = kind == SEG_OFF;              // a segment outside the mask: identity rows, x = in
-    if (pad || off) {                              // identity block: nothing reaches the real segments
-        k.gF = k.aF = k.cF = k.gL = k.aL = k.cL = 0.0;
-        kappa = 0.0; aS = 0.0; bS = 1.0; cS = 0.0;
-        if (pad) d[M - 1] = 0.0;
-    }
-    double2 bmod = make_double2(1.0, 1.0);
-    if constexpr (MIXED) {
-        if (kind >= SEG_TAIL)                      // the surface crosses the segment once (adi_core.hpp, mixed_*)
-            mixed_lane_condense<M, HAS_Q>(kind, Lm, U, s, coeff + base + (long)r0 * g.stride,
-                                          HAS_Q ? qf + base + (long)r0 * g.stride : qf, g.stride, a0, b0, d, bmod, k);
-    }
-    double xL, xS;
-    tile_separators(sm, tid, kk, sg, Lp, LINES, aS, bS, cS, d[M - 1], k, xL, xS);
-    if (kind == SEG_UNI || kind == SEG_PAD) back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
-    else if constexpr (MIXED) {
-        if (kind >= SEG_TAIL) mixed_lane_back_solve<M>(kind, Lm, U, bmod, a0, d, xL, xS);
-    }
-    if (pad) return;                               // (after the last barrier)
-    double *out_t = out + tbase;
-    if (FUSE || (kBufStrided && (long)g.n * g.stride * 8 < 0x7fffffffL)) {
-        const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)out_t, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-        for (int r = 0; r < M; ++r) buf_store_f64(rO, voff * 8u, (unsigned)r * (unsigned)(g.stride * 8), d[r]);
-    } else {
-#pragma unroll
-        for (int r = 0; r < M; ++r) (out_t + (size_t)r * g.stride)[voff] = d[r];
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // K4: generic fallback, one thread per line, normalised Thomas (adi3d_gpu_coeff.py:140-152) with the
@@ -282,21 +176,6 @@ __global__ __launch_bounds__(256) void k_sweep_generic(
 // ------------------------------------------------------------------------------------------------
 // host-side launch logic
 // ------------------------------------------------------------------------------------------------
-template <int MF, bool HAS_DIR, bool HAS_Q, bool FUSE>
-static void launch_strided_fast(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
-                                const uint8_t *dmask, const double *dval, const double *qf, double *out,
-                                const LineGeom &g, const double *xlo, const double *xhi, SweepScal s, unsigned *queue,
-                                hipStream_t st, const Fuse &fz)
-{
-    if (s.box && MF <= 16) // all-solid box (caller's hint): the build without surface-segment lanes (fused: no spills)
-        hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE, (MF > 16)>), dim3((unsigned)P.ntiles_f),
-                           dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
-                           P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
-    else
-        hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE, true>), dim3((unsigned)P.ntiles_f),
-                           dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
-                           P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
-}
 
 template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE>
 static void launch_strided(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
@@ -309,7 +188,9 @@ static void launch_strided(const StridedPlan &P, const double *in, const uint8_t
         const bool nofb = s.nofb != 0;                 // promise: no tile will be queued (see SweepScal)
         if (nofb) queue = nullptr;
         else (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
-        if (P.Mf == 32) launch_strided_fast<32, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
+        if (P.Mf == 20 || P.Mf == 24 || P.Mf == 28)      // exact fits: instantiated in adi_sweep_strided_x.hip
+            strided_fast_exact(P.Mf, HAS_DIR, HAS_Q, P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
+        else if (P.Mf == 32) launch_strided_fast<32, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         else if (P.Mf == 16) launch_strided_fast<16, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         else launch_strided_fast<8, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         ggrid = P.ntiles_g < 1024 ? (unsigned)P.ntiles_g : 1024u;

@@ -361,7 +361,11 @@ def test_fused_explicit_sweep0_is_bit_identical(hip, shape, fill, bc):
     for variant, dense in ((None, False), (_lib.SWEEP_GENERAL, True)):
         two = hip.adi_sweep_axis(0, R0, grid, mat, prm, packs[0], Tinf=25.0, variant=variant, dense=dense)
         one = hip.adi_explicit_sweep_axis0(T0, grid, mat, prm, packs[0], Tinf=25.0, variant=variant, dense=dense)
-        if shape[2] % 16 == 0 or dense:
+        # lines of 320 / 384 rows: the unfused FAST kernel cuts them into 16 segments of 20 / 24 rows (exact fit,
+        # adi_sweep_strided_x.hip), the fused one -- 16 rows per thread at most -- into 20 / 24 segments of 16: two
+        # partitions of the same systems, equal to rounding
+        exact_fit = shape[0] in (320, 384, 448, 640, 768, 896) and not dense
+        if (shape[2] % 16 == 0 or dense) and not exact_fit:
             # the same kernel pair (FAST interior tiles, GENERAL surface tiles) serves both forms: bit-identical
             assert np.array_equal(one, two), (variant, dense, float(np.abs(one - two).max()))
         else:
@@ -648,3 +652,37 @@ def test_no_fallback_promise_is_learnt_per_configuration(hip):
     want2, _, _ = run(orc, holes, 3)
     assert rel_linf(got2, want2) <= TOL
     assert not all(v is True for p in pk2 for v in p._nofb.values())
+
+
+@pytest.mark.parametrize('n', [320, 384, 448, 640, 768, 896, 1280])
+@pytest.mark.parametrize('ax', [0, 1, 2])
+def test_exact_fit_row_counts(hip, n, ax):
+    """lines whose length is 20, 24 or 28 times a power of two: the FAST kernels take 20 / 24 / 28 rows per lane (thread) so
+    that the line fills the lanes of the interface solve exactly (adi_sweep_contig_x.hip, adi_sweep_strided_x.hip).  Solid
+    blocks, voids, a curved solid and the general pack, against the oracle."""
+    from oracle import adi_oracle as orc
+    alpha = 54.0 / (7800.0 * 490.0)
+    for kind in ('solid', 'holes', 'ellipsoid', 'general'):
+        rng = np.random.default_rng(n + ax)
+        shape = [12, 16, 20]
+        shape[ax] = n
+        if ax != 2:
+            shape[2] = 32
+        shape = tuple(shape)
+        mask = np.ones(shape, bool)
+        if kind == 'holes':
+            mask = rng.random(shape) > 0.03
+        if kind == 'ellipsoid':
+            g = np.meshgrid(*[(np.arange(s) + 0.5) / s - 0.5 for s in shape], indexing='ij')
+            mask = (g[0] ** 2 + g[1] ** 2 + g[2] ** 2) <= 0.23
+        dm = dv = neu = None
+        if kind == 'general':
+            dm = np.zeros(shape, bool); dm[:, 0, :] = True
+            dv = 77.0
+            neu = {'x+': 1e5, 'z-': rng.uniform(0, 1e5, shape)}
+        dx = 1e-3
+        c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask, T0=rng.uniform(20.0, 1500.0, shape),
+                 dir_mask=dm, dir_value=dv, neumann=neu, robin_h=350.0, Tinf=20.0, theta=0.5, dt=150.0 * dx * dx / alpha,
+                 nsteps=2, births=None)
+        err = rel_linf(run_cart_case(hip, c)['T_final'], run_cart_case(orc, c)['T_final'])
+        assert err <= TOL, (n, ax, kind, err)
