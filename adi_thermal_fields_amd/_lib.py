@@ -81,6 +81,9 @@ SIGNATURES = {
     'adi_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_pp, c_void_p, c_void_p,
                          c_void_pp, c_int, c_int, c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double,
                          c_double, c_double, c_double, c_void_p, c_size_t, c_void_p]),
+    'adi_step_queued': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_pp, c_void_p, c_void_p,
+                         c_void_pp, c_int, c_int, c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double,
+                         c_double, c_double, c_double, c_void_p, c_size_t, c_void_p, c_void_p]),
     'adi_morph6': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'adi_flood_outside': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int_p, c_void_p]),
     'adi_pack_frame_f32be': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p]),

@@ -185,11 +185,15 @@ int adi_explicit_condense0(int variant, const double *d_T, long valid_lo, long v
     return condense_entry(0, variant, d_T, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
                           sparse, theta, gam, dt, Tinf, d_cond, d_work, work_bytes, stream, &fz);
 }
-int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b, const uint8_t *d_flags,
-             const double *const *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
-             const double *const *d_qflux, int variant, int sparse, int nx, int ny, int nz, long plane_stride,
-             double dx, double rho, double cp, double k, double dt, double theta, double Tinf, void *d_work,
-             size_t work_bytes, void *stream)
+}  // extern "C"
+
+// h_queued (optional, 3 host words): the first word of the workspace after each sweep = the number of units its FAST kernel
+// queued (copied on the stream; valid once the stream has been synchronised)
+static int step_impl(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b, const uint8_t *d_flags,
+                     const double *const *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
+                     const double *const *d_qflux, int variant, int sparse, int nx, int ny, int nz, long plane_stride,
+                     double dx, double rho, double cp, double k, double dt, double theta, double Tinf, void *d_work,
+                     size_t work_bytes, void *stream, unsigned *h_queued)
 {
     ADI_REQUIRE(d_T_in && d_T_out && d_tmp_a && d_tmp_b && d_coeff, "adi_step: null argument");
     ADI_REQUIRE(d_tmp_a != d_tmp_b && d_tmp_a != d_T_in && d_tmp_b != d_T_in && d_T_out != d_tmp_a && d_T_out != d_T_in,
@@ -211,8 +215,41 @@ int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_t
         rc = adi_sweep(0, variant, d_tmp_a, d_flags, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_b, nullptr, nullptr, d_work, work_bytes, stream);
     }
     if (rc) return rc;
+    auto report = [&](int axis) {
+        if (h_queued != nullptr) (void)hipMemcpyAsync(h_queued + axis, d_work, sizeof(unsigned), hipMemcpyDeviceToHost, as_stream(stream));
+    };
+    report(0);
     rc = adi_sweep(1, variant, d_tmp_b, d_flags, d_coeff[1], d_dir_mask, d_dir_val, q1, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_a, nullptr, nullptr, d_work, work_bytes, stream);
     if (rc) return rc;
-    return adi_sweep(2, variant, d_tmp_a, d_flags, d_coeff[2], d_dir_mask, d_dir_val, q2, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_T_out, nullptr, nullptr, d_work, work_bytes, stream);
+    report(1);
+    rc = adi_sweep(2, variant, d_tmp_a, d_flags, d_coeff[2], d_dir_mask, d_dir_val, q2, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_T_out, nullptr, nullptr, d_work, work_bytes, stream);
+    if (rc) return rc;
+    report(2);
+    return ADI_OK;
+}
+
+extern "C" {
+
+int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b, const uint8_t *d_flags,
+             const double *const *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
+             const double *const *d_qflux, int variant, int sparse, int nx, int ny, int nz, long plane_stride,
+             double dx, double rho, double cp, double k, double dt, double theta, double Tinf, void *d_work,
+             size_t work_bytes, void *stream)
+{
+    return step_impl(d_T_in, d_T_out, d_tmp_a, d_tmp_b, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, variant, sparse, nx, ny,
+                     nz, plane_stride, dx, rho, cp, k, dt, theta, Tinf, d_work, work_bytes, stream, nullptr);
+}
+
+int adi_step_queued(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b, const uint8_t *d_flags,
+                    const double *const *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
+                    const double *const *d_qflux, int variant, int sparse, int nx, int ny, int nz, long plane_stride,
+                    double dx, double rho, double cp, double k, double dt, double theta, double Tinf, void *d_work,
+                    size_t work_bytes, void *stream, unsigned *h_queued)
+{
+    ADI_REQUIRE(h_queued && d_work && work_bytes >= sizeof(unsigned), "adi_step_queued: needs a workspace and three host words");
+    ADI_REQUIRE((sparse & 4) == 0, "adi_step_queued: the no-fallback promise skips the queue it is asked to report");
+    h_queued[0] = h_queued[1] = h_queued[2] = 0xffffffffu;
+    return step_impl(d_T_in, d_T_out, d_tmp_a, d_tmp_b, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, variant, sparse, nx, ny,
+                     nz, plane_stride, dx, rho, cp, k, dt, theta, Tinf, d_work, work_bytes, stream, h_queued);
 }
 }  // extern "C"

@@ -42,6 +42,7 @@ struct adi_ctx {
     int variant;         // ADI_SWEEP_* chosen at build_coeffs time
     bool have_mask, have_packs, have_T;
     bool all_solid;      // every cell in the mask: passed to adi_step as the box hint (bit 1 of `sparse`)
+    int promise;         // no-fallback promise (bit 2 of `sparse`): -1 not known for this mask / these packs, 0 no, 1 yes
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     float last_ms;
@@ -161,6 +162,7 @@ int adi_ctx_set_mask(adi_ctx *c, const uint8_t *h_mask)
     for (size_t i = 0; i < cells && all; ++i) all = h_mask[i] != 0;
     c->all_solid = all;
     c->have_mask = true;
+    c->promise = -1;
     c->have_packs = false;  // packs depend on the mask: rebuild before the next step
     return ADI_OK;
 }
@@ -222,6 +224,7 @@ int adi_ctx_build_coeffs(adi_ctx *c, double rho, double cp, const int *h_mode, c
     if (es != hipSuccess) return set_err(ADI_ERR_HIP, "adi_ctx_build_coeffs: %s", hipGetErrorString(es));
     c->variant = has_dir ? (has_q ? ADI_SWEEP_GENERAL : ADI_SWEEP_NO_Q) : (has_q ? ADI_SWEEP_NO_DIR : ADI_SWEEP_LEAN);
     c->have_packs = true;
+    c->promise = -1;
     return ADI_OK;
 }
 
@@ -265,10 +268,24 @@ int adi_ctx_step(adi_ctx *c, double rho, double cp, double k, double dt, double 
     ADI_HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (int s = 0; s < nsteps; ++s) {
         const int nxt = c->cur ^ 1;
-        int rc = adi_step(c->T[c->cur], c->T[nxt], c->tmp[0], c->tmp[1], c->flags, c->coeff, c->dir_mask, c->dir_val,
-                          c->qflux, c->variant, 1 | (c->all_solid ? 2 : 0), c->nx, c->ny, c->nz, c->sx, c->dx, rho, cp, k, dt, theta, Tinf, c->work,
-                          c->work_bytes, c->stream);
-        if (rc != ADI_OK) return rc;
+        const int sp = 1 | (c->all_solid ? 2 : 0);
+        int rc;
+        if (c->promise < 0 && c->work != nullptr && c->work_bytes >= sizeof(unsigned)) {
+            // first step after a mask / pack change: count the units each sweep's FAST kernel queues (a function of the mask
+            // and the packs, not of the field); if there are none, the later steps skip the queue reset and the fallback launch
+            unsigned q[3];
+            rc = adi_step_queued(c->T[c->cur], c->T[nxt], c->tmp[0], c->tmp[1], c->flags, c->coeff, c->dir_mask, c->dir_val,
+                                 c->qflux, c->variant, sp, c->nx, c->ny, c->nz, c->sx, c->dx, rho, cp, k, dt, theta, Tinf,
+                                 c->work, c->work_bytes, c->stream, q);
+            if (rc != ADI_OK) return rc;
+            ADI_HIP_TRY(hipStreamSynchronize(c->stream));
+            c->promise = (q[0] == 0 && q[1] == 0 && q[2] == 0) ? 1 : 0;
+        } else {
+            rc = adi_step(c->T[c->cur], c->T[nxt], c->tmp[0], c->tmp[1], c->flags, c->coeff, c->dir_mask, c->dir_val, c->qflux,
+                          c->variant, sp | (c->promise == 1 ? 4 : 0), c->nx, c->ny, c->nz, c->sx, c->dx, rho, cp, k, dt, theta, Tinf,
+                          c->work, c->work_bytes, c->stream);
+            if (rc != ADI_OK) return rc;
+        }
         c->cur = nxt;
     }
     ADI_HIP_TRY(hipEventRecord(c->ev1, c->stream));

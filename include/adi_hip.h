@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 9
+#define ADI_ABI_VERSION 10
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -248,6 +248,15 @@ int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_t
              const double *d_dir_val, const double *const *d_qflux, int variant, int sparse,
              int nx, int ny, int nz, long plane_stride, double dx, double rho, double cp, double k,
              double dt, double theta, double Tinf, void *d_work, size_t work_bytes, void *stream);
+/* The same step, reporting in h_queued[axis] (three HOST words, valid once the stream is synchronised) how many units the
+ * FAST kernel of each sweep handed to the GENERAL kernel.  That number depends on the flags, the Dirichlet mask, the
+ * variant, `sparse` and the shape only, so three zeros license bit 2 of `sparse` (the no-fallback promise, see adi_sweep) on
+ * every later step of the same configuration; adi_ctx_step does this on the first step after a mask / pack change. */
+int adi_step_queued(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b,
+             const uint8_t *d_flags, const double *const *d_coeff, const uint8_t *d_dir_mask,
+             const double *d_dir_val, const double *const *d_qflux, int variant, int sparse,
+             int nx, int ny, int nz, long plane_stride, double dx, double rho, double cp, double k,
+             double dt, double theta, double Tinf, void *d_work, size_t work_bytes, void *stream, unsigned *h_queued);
 
 /*
  * The callers either side of the path.  Masks here are DENSE uint8 (nx, ny, nz), C order.

@@ -58,3 +58,48 @@ def test_device_info():
     cu = ctypes.c_int(0); hbm = ctypes.c_size_t(0); lds = ctypes.c_size_t(0)
     _lib.check(_lib.lib.adi_device_info(0, name, ctypes.byref(cu), ctypes.byref(hbm), ctypes.byref(lds)))
     assert b'gfx950' in name.value and cu.value == 256
+
+
+@pytest.mark.parametrize('kind', ['solid', 'holes'])
+def test_ctx_learns_the_no_fallback_promise(kind):
+    """adi_ctx_step counts the units each sweep queues on the first step after a mask / pack change (adi_step_queued) and,
+    when there are none, runs the later steps without the queue reset and the fallback launch.  Same numbers either way:
+    several calls on a solid box (nothing queued: promise taken) and on a box with voids (units queued: never promised),
+    a mask change in between, all against the oracle."""
+    from adi_thermal_fields_amd import _lib
+    from oracle import adi_oracle as orc
+    lib = _lib.lib
+    shape = (256, 16, 32)
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    dt = 60.0 * dx * dx / alpha
+    rng = np.random.default_rng(11)
+    T0 = rng.uniform(20.0, 900.0, shape)
+    masks = [np.ones(shape, bool), rng.random(shape) > 0.05] if kind == 'solid' else [rng.random(shape) > 0.05, np.ones(shape, bool)]
+    ctx = ctypes.c_void_p()
+    _lib.check(lib.adi_ctx_create(*shape, dx, 0, ctypes.byref(ctx)))
+    try:
+        hm = (ctypes.c_int * 6)(1, 1, 1, 1, 1, 1)
+        hs = (ctypes.c_double * 6)(*([300.0] * 6))
+        qm = (ctypes.c_int * 6)(0, 0, 0, 0, 0, 0)
+        qs = (ctypes.c_double * 6)(0, 0, 0, 0, 0, 0)
+        T = np.ascontiguousarray(T0)
+        want = np.array(T0)
+        for mask in masks:
+            m8 = np.ascontiguousarray(mask).view(np.uint8)
+            _lib.check(lib.adi_ctx_set_mask(ctx, m8.ctypes.data))
+            _lib.check(lib.adi_ctx_build_coeffs(ctx, 7800.0, 490.0, hm, hs, None, qm, qs, None, None, None))
+            _lib.check(lib.adi_ctx_upload_T(ctx, T.ctypes.data))
+            for nsteps in (1, 3, 2):                    # the first call learns, the others use what it learnt
+                _lib.check(lib.adi_ctx_step(ctx, 7800.0, 490.0, 54.0, dt, 0.5, 20.0, nsteps))
+            got = np.empty(shape)
+            _lib.check(lib.adi_ctx_download_T(ctx, got.ctypes.data))
+            og = orc.Grid3D(*shape, dx, mask)
+            om = orc.Material(7800.0, 490.0, 54.0); op = orc.Params(dt, 0.5)
+            pk = orc.precompute_coeff_packs_unified(og, om, robin_h=300.0)
+            for _ in range(6):
+                want = orc.adi_step_numba_coeff(want, og, om, op, pk, Tinf=20.0)
+            assert rel_linf(got, want) <= 1e-10
+            T = np.ascontiguousarray(got)
+    finally:
+        lib.adi_ctx_destroy(ctx)
