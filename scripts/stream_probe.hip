@@ -174,7 +174,7 @@ static int run_rw(const char *name, const double *in, double *out, int n, long s
 }
 
 template <int M, int LPT, int LINES, bool NJ, int THREADS, int OCC>
-static int run(const char *name, const double *in, double *out, int n, long sx)
+static int run(const char *name, const double *in, double *out, int n, long sx, size_t dyn_lds = 0)
 {
     static_assert(THREADS == (LINES / LPT) * (512 / M), "threads");
     const int tiles_inner = n / LINES;
@@ -184,7 +184,7 @@ static int run(const char *name, const double *in, double *out, int n, long sx)
     std::vector<float> ts;
     for (int it = 0; it < 12; ++it) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((k_tile<M, LPT, LINES, NJ, THREADS, OCC>), dim3((unsigned)ntiles), dim3(THREADS), 0, 0, in, out, n, n, n, sx, ntiles, tiles_inner);
+        hipLaunchKernelGGL((k_tile<M, LPT, LINES, NJ, THREADS, OCC>), dim3((unsigned)ntiles), dim3(THREADS), dyn_lds, 0, in, out, n, n, n, sx, ntiles, tiles_inner);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -215,6 +215,11 @@ int main()
     if (run_jpair<16, 16, 512, 1>("jpair M=16 lines=16 thr=512 occ=1", a, b, n, sx)) return 1;
     if (run_jpair<8, 16, 1024, 1>("jpair M=8 lines=16 thr=1024 occ=1", a, b, n, sx)) return 1;
     if (run_jpair<16, 8, 256, 2>("jpair M=16 lines=8 thr=256 occ=2", a, b, n, sx)) return 1;
+    // the same skeleton held to 2 and 1 workgroups per CU by dynamic LDS (the real fused kernel runs 2 per CU at 128 VGPRs)
+    if (run<16, 1, 16, true, 512, 2>("M=16 lines=16 nj=true, 2 workgroups per CU", a, b, n, sx, 72 * 1024)) return 1;
+    if (run<16, 1, 16, true, 512, 2>("M=16 lines=16 nj=true, 1 workgroup per CU", a, b, n, sx, 150 * 1024)) return 1;
+    if (run<16, 1, 16, true, 512, 2>("M=16 lines=16 nj=true, 3 workgroups per CU", a, b, n, sx, 50 * 1024)) return 1;
+    if (run<16, 1, 16, false, 512, 2>("M=16 lines=16 nj=false, 2 workgroups per CU", a, b, n, sx, 72 * 1024)) return 1;
     RUN(16, 1, 16, false, 512, 2);
     RUN(16, 1, 16, true, 512, 2);
     RUN(32, 1, 32, false, 512, 2);
