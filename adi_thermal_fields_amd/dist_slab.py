@@ -462,6 +462,12 @@ class SlabStepper:
         return ['halo+explicit', 'sweep_axis0_distributed', 'sweep_axis1', 'sweep_axis2_contig']
 
     @property
+    def pass_a_form(self):
+        """how pass A of the sharded-axis sweep runs under the current plan (bench.py reports it)"""
+        p = self._a0 or {}
+        return 'dots_in_explicit' if p.get('dots') else ('fused' if p.get('fused') else 'separate')
+
+    @property
     def stage_bytes_per_cell(self):
         """algorithmic HBM bytes per local cell of the stages (pass A re-reads the inputs of the rows it covers)"""
         bpc = self._bpc

@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: ADI steps/s and HBM GB/s, 512^3 fp64 Cartesian Robin, 1..8 MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 512] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 512] [--scaling weak|strong] [--mask box|ellipsoid] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+
+Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) this process touches no GPU: it starts the N
+ranks itself as fresh child processes (torch.distributed.run, one per GPU), relays rank 0's JSON line and exits
+non-zero with the failing rank's tail if a rank fails or the run exceeds --launch-timeout.
 
 One "step" = one full ADI time step (explicit stage + three implicit sweeps) of the hot path over a
 synthetic field that is already resident in HBM.  Workload (BASELINE.json configs[2] / SURVEY.md 8(d)
 config 3): n^3 cells per GPU (n = 512), all-solid mask, dx = 5e-4, steel, Robin h = 500 on all six faces,
-Tinf = 20, theta = 0.5, cfl = 200, T0 ~ U(20, 1000) seeded per rank.  For N > 1 the grid is (N*n, n, n)
-cut into slabs along memory axis 0 (weak scaling): halo planes for the explicit stage and the reduced
-interface system of the sharded-axis sweep travel over RCCL.
+Tinf = 20, theta = 0.5, cfl = 200, T0 ~ U(20, 1000) seeded per rank.  For N > 1 the grid is cut into slabs along
+memory axis 0: (N*n, n, n) with --scaling weak (the default: n^3 cells per GPU), (n, n, n) with --scaling strong
+(BASELINE.json configs[2]: 512^3 over 8 GPUs = 64 planes per GPU).  Halo planes for the explicit stage and the
+reduced interface system of the sharded-axis sweep travel over RCCL.
 
 Prints ONE JSON line on rank 0.  `value` = 512^3-cell-equivalent ADI steps per second summed over all
 ranks (= plain steps/s at N = 1, n = 512).
@@ -30,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)      # >= 10 warm-up + >= 50 timed steps
@@ -47,30 +52,128 @@ def parse():
     ap.add_argument('--rehearse-world', type=int, default=0,
                     help='one GPU only: run the code path of a middle rank of a W-GPU job with a loopback communicator '
                          '(no wire time); the line is marked "rehearsal" and is not a measurement of W GPUs')
-    return ap.parse_args()
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='N > 1: weak = n^3 cells per GPU, global (N*n, n, n) (default); strong = n^3 cells in total, '
+                         'n/N planes per GPU (BASELINE.json configs[2]: 512^3 over 8 GPUs = 64 planes each)')
+    ap.add_argument('--mask', choices=['box', 'ellipsoid'], default='box',
+                    help='box: all-solid (the headline workload); ellipsoid: the same box holding a curved solid '
+                         '(semi-axes 0.47 / 0.49 / 0.48 of the box), i.e. every in-mask line crosses the surface twice')
+    ap.add_argument('--launch-timeout', type=float, default=1500.0,
+                    help='seconds the self-started ranks of a plain `--gpus N` run may take before they are killed')
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(n, seed=0, steps_1t=3, steps_all=9):
+# ---- plain `python bench.py --gpus N`: this process starts the ranks -------------------------------------------------
+def launch_ranks(nproc, script, script_args, timeout_s, extra_env=None):
+    """Start `nproc` ranks of `script` as CHILD processes through torch.distributed.run (one per GPU, rendezvous on
+    127.0.0.1 at a free port), wait for them and return (exit code, the last JSON line a rank wrote to stdout or None,
+    tail of the ranks' stderr).  The caller has not touched the GPU and nothing is exec'ed in its place.  A run that
+    exceeds `timeout_s` is ended by killing the process GROUP this call created (never a pattern) and reports 124."""
+    import signal
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), script] + list(script_args)
+    with tempfile.TemporaryFile(mode='w+') as ferr:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=ferr, text=True, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=timeout_s)
+            rc = p.returncode
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGTERM)
+                out, _ = p.communicate(timeout=20)
+            except (subprocess.TimeoutExpired, ProcessLookupError):
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                out, _ = p.communicate()
+            rc = 124
+        ferr.seek(0)
+        err = ferr.read()
+    line = None
+    for ln in (out or '').splitlines():
+        ln = ln.strip()
+        if ln.startswith('{') and ln.endswith('}'):
+            try:
+                if 'metric' in json.loads(ln):
+                    line = ln
+            except ValueError:
+                pass
+    return rc, line, '\n'.join(err.splitlines()[-60:])
+
+
+def launch_self(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks, relay rank 0's line."""
+    rc, line, tail = launch_ranks(a.gpus, os.path.abspath(__file__), argv, a.launch_timeout)
+    if rc == 0 and line is not None:
+        print(line, flush=True)
+        return 0
+    why = ('timed out after %.0f s (--launch-timeout)' % a.launch_timeout if rc == 124 else
+           'exit code %d' % rc if rc != 0 else 'no JSON line from rank 0')
+    print('bench.py --gpus %d: the ranks started with torch.distributed.run failed: %s\n---- tail of the ranks\' stderr '
+          '----\n%s' % (a.gpus, why, tail), file=sys.stderr, flush=True)
+    return rc if rc != 0 else 1
+
+
+def need_gpu(rank):
+    if not torch.cuda.is_available():
+        print('bench.py rank %d: no GPU visible (torch.cuda.is_available() is False); the benchmark has no CPU path'
+              % rank, file=sys.stderr, flush=True)
+        sys.exit(3)
+
+
+def make_mask(kind, shape, i0=0, nx_global=None):
+    """mask of planes [i0, i0 + shape[0]) of a (nx_global, ny, nz) grid: all-solid box, or an ellipsoid with semi-axes
+    0.47 / 0.49 / 0.48 of the box (a curved solid: every in-mask line crosses the surface twice)"""
+    nxl, ny, nz = shape
+    nxg = nxl if nx_global is None else nx_global
+    if kind == 'box':
+        return np.ones(shape, bool)
+    x = ((np.arange(i0, i0 + nxl) + 0.5) / nxg - 0.5) / 0.47
+    y = ((np.arange(ny) + 0.5) / ny - 0.5) / 0.49
+    z = ((np.arange(nz) + 0.5) / nz - 0.5) / 0.48
+    return (x[:, None, None] ** 2 + y[None, :, None] ** 2 + z[None, None, :] ** 2) <= 1.0
+
+
+def cpu_baseline(n, mask=None, T0=None, seed=0, steps_1t=3, steps_all=9):
     """The oracle (oracle/adi_oracle.c, a port of the reference's Numba path) timed on this host's cores on a bounded
     sample of the same workload: n^3 cells (default 512) x `steps_1t` steps on ONE thread -- the
     reference's kernels are serial -- and x `steps_all` steps on all cores (OpenMP over lines, working set first-touched
-    in parallel).  Returns (single-thread dict, all-cores dict)."""
+    in parallel).  `mask` / `T0`: the mask and the initial field of the timed workload (so that the single-thread leg's
+    field after `steps_1t` steps can be compared with the GPU's).  Returns (single-thread dict, all-cores dict, field
+    after `steps_1t` steps)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from oracle import adi_oracle as orc
     shape = (n, n, n)
-    grid = orc.Grid3D(n, n, n, 5e-4, np.ones(shape, bool))
+    grid = orc.Grid3D(n, n, n, 5e-4, np.ones(shape, bool) if mask is None else mask)
     mat = orc.Material(7800.0, 490.0, 54.0)
     alpha = mat.k / (mat.rho * mat.cp)
     prm = orc.Params(200.0 * grid.dx ** 2 / alpha, 0.5)
     packs = orc.precompute_coeff_packs_unified(grid, mat, robin_h=500.0, _share=True)
-    T0 = np.random.default_rng(seed).uniform(20.0, 1000.0, shape)
+    if T0 is None:
+        T0 = np.random.default_rng(seed).uniform(20.0, 1000.0, shape)
     out = []
+    field = None
     for omp, steps in ((False, steps_1t), (True, steps_all)):
         if omp:
             orc.adi_run(T0, grid, mat, prm, packs, Tinf=20.0, nsteps=1, omp=True)   # warm the OpenMP pool
         t0 = time.perf_counter()
-        orc.adi_run(T0, grid, mat, prm, packs, Tinf=20.0, nsteps=steps, omp=omp)
+        res = orc.adi_run(T0, grid, mat, prm, packs, Tinf=20.0, nsteps=steps, omp=omp)
         dt = time.perf_counter() - t0
+        if not omp:
+            field = res
+        del res
         cells_per_s = steps * n ** 3 / dt
         out.append(dict(value=cells_per_s / 512 ** 3, unit='steps/s (512^3-cell equivalent)',
                         cores=(os.cpu_count() if omp else 1), kind='port',
@@ -78,7 +181,7 @@ def cpu_baseline(n, seed=0, steps_1t=3, steps_all=9):
                                % (n, steps, dt, '_omp' if omp else '',
                                   ' (time includes the parallel first-touch copy of the working set)' if omp else ''),
                         cell_updates_per_s=cells_per_s))
-    return out
+    return out[0], out[1], field
 
 
 # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout of every process that
@@ -112,6 +215,7 @@ def main_cyl(a):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == a.gpus, 'WORLD_SIZE (%d) != --gpus (%d)' % (world, a.gpus)
+    need_gpu(rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
@@ -220,9 +324,13 @@ def measured_traffic(kernel, config='cart'):
         return None
 
 
-def main():
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    a = parse(argv)
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started plainly: this process stays off the GPU and starts the ranks as fresh children
+        sys.exit(launch_self(a, argv))
     claim_stdout()
-    a = parse()
     if a.config == 'cyl':
         return main_cyl(a)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -231,11 +339,8 @@ def main():
     force_dist = a.force_dist and world == 1
     multi = world > 1 or rehearse > 1 or force_dist   # the slab code path
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if a.gpus > 1 and world == 1:
-        print('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % a.gpus,
-              file=sys.stderr)
-        sys.exit(2)
     assert world == a.gpus, 'WORLD_SIZE (%d) != --gpus (%d)' % (world, a.gpus)
+    need_gpu(rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
@@ -256,14 +361,29 @@ def main():
     dx = 5e-4
     prm = adi.Params(200.0 * dx * dx / alpha, 0.5)
     Tinf = 20.0
-    gen = torch.Generator(device=dev); gen.manual_seed(1 + rank)
-    T0 = torch.rand((n, n, n), dtype=torch.float64, device=dev, generator=gen) * 980.0 + 20.0
+    # this rank's slab: planes [i0, i0 + nxl) of a (nxg, n, n) grid
+    W, r = (rehearse, rehearse // 2) if rehearse else (world, rank)
+    if a.scaling == 'strong' and W > 1:
+        from adi_thermal_fields_amd.dist_slab import split_planes
+        sizes = split_planes(n, W)
+        nxg, nxl, i0 = n, sizes[r], sum(sizes[:r])
+    else:
+        nxg, nxl, i0 = W * n, n, r * n
+    shape = (nxl, n, n)
+    mask = make_mask(a.mask, shape, i0, nxg)
+    T0_host = None
+    if not multi:
+        # host field from a NumPy seed: the CPU-baseline leg starts the oracle from the same array (parity_rel_linf)
+        T0_host = np.random.default_rng(1).uniform(20.0, 1000.0, shape)
+        T = adi.to_device(T0_host)
+    else:
+        gen = torch.Generator(device=dev); gen.manual_seed(1 + rank)
+        T = adi.DeviceField(torch.rand(shape, dtype=torch.float64, device=dev, generator=gen) * 980.0 + 20.0)
 
     stage_names = ['explicit', 'sweep_axis0', 'sweep_axis1', 'sweep_axis2_contig']
     if not multi:
-        grid = adi.Grid3D(n, n, n, dx, np.ones((n, n, n), bool))
+        grid = adi.Grid3D(n, n, n, dx, mask)
         packs = adi.precompute_coeff_packs_unified(grid, mat, robin_h=500.0)
-        T = adi.DeviceField(T0)
         stepper = adi.StagedStepper(grid, mat, prm, packs, Tinf)
         stage_names = stepper.stage_names      # explicit stage folded into the axis-0 sweep where supported
         variant = packs[0].variant
@@ -272,11 +392,7 @@ def main():
         comm = None
         if rehearse:      # a middle rank of `rehearse`: loopback copies, or (--force-dist) RCCL send/recv to itself
             comm = (dist_slab.SelfLoopDistComm if force_dist else dist_slab.LoopbackComm)(rehearse, rehearse // 2)
-        stepper = dist_slab.SlabStepper.from_local(T0, np.ones((n, n, n), bool), dx, mat, prm, Tinf,
-                                                   robin_h=500.0, comm=comm)
-        if os.environ.get('ADI_SLAB_CHUNK_EDGES'):        # tuning knob, e.g. "0.125,0.5"
-            stepper.SLAB_CHUNK_EDGES = tuple(float(x) for x in os.environ['ADI_SLAB_CHUNK_EDGES'].split(','))
-        T = adi.DeviceField(T0)
+        stepper = dist_slab.SlabStepper.from_local(T.t, mask, dx, mat, prm, Tinf, robin_h=500.0, comm=comm)
         variant = stepper.variant
         overlap_err, overlap_on = stepper.self_check(T)     # pipeline on the second stream vs plain ordering
 
@@ -286,6 +402,7 @@ def main():
         torch.cuda.synchronize()
 
     kw = dict(prefetch_halo=True) if multi else {}     # the loop feeds every step's output to the next unmodified
+    T_start = T
     for _ in range(a.warmup):
         T = stepper.step(T, **kw)
     if multi:
@@ -308,7 +425,7 @@ def main():
 
     stage_ms = np.array([[ev[s][i].elapsed_time(ev[s][i + 1]) for i in range(nst)] for s in range(a.steps)])
     mean_ms = stage_ms.mean(axis=0)
-    N = n ** 3
+    N = nxl * n * n                                    # cells of this rank
     bytes_per_cell = dict(zip(stage_names, stepper.stage_bytes_per_cell))
     kernels = {}
     for i, nm in enumerate(stage_names):
@@ -320,17 +437,20 @@ def main():
     # what every rank measured, so that the SCALE record shows what RCCL saw: the world size from the process group itself,
     # every rank's stage times and the payload each rank handed to the transport per step
     ranks_info = None
+    total_cells = float(N)
     if world > 1 or force_dist:
         comm = stepper.comm
         mine = torch.tensor(list(mean_ms) + [float(getattr(comm, 'bytes_sent', 0)), float(getattr(comm, 'n_exchanges', 0)),
-                                             float(t1 - t0)], dtype=torch.float64, device=dev)
+                                             float(t1 - t0), float(N)], dtype=torch.float64, device=dev)
         allr = torch.empty(dist.get_world_size() * mine.numel(), dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(allr, mine)
         allr = allr.view(dist.get_world_size(), -1).cpu().numpy()
+        total_cells = float(allr[:, nst + 3].sum())
         nsteps_counted = a.steps + max(a.warmup, 1) + 2            # the counters run from construction (incl. self-check)
         ranks_info = dict(world_size_from_process_group=dist.get_world_size(), backend=dist.get_backend(),
                           stage_ms_per_rank={nm: [round(float(v), 4) for v in allr[:, i]] for i, nm in enumerate(stage_names)},
                           loop_seconds_per_rank=[round(float(v), 4) for v in allr[:, nst + 2]],
+                          cells_per_rank=[int(v) for v in allr[:, nst + 3]],
                           mbytes_sent_per_rank_total=[round(float(v) / 1e6, 2) for v in allr[:, nst]],
                           exchanges_per_rank_total=[int(v) for v in allr[:, nst + 1]],
                           note='byte / exchange counters cover %d steps (warm-up, self-check and timed loop)' % nsteps_counted)
@@ -361,30 +481,38 @@ def main():
             m = float(np.mean(ms))
             xs[nm] = dict(ms=round(m, 4), bytes_per_cell=42, achieved_gbs=round(42 * N / (m * 1e-3) / 1e9, 1),
                           frac=round(42 * N / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        del out, tin
 
     dom = max(kernels, key=lambda k: kernels[k]['ms'])
-    traffic = measured_traffic(dom, 'cart')
+    traffic = measured_traffic(dom, 'cart') if a.mask == 'box' else None
     ms_per_step = elapsed / a.steps * 1e3
-    value = world * N / 512 ** 3 * a.steps / elapsed
+    ranks_in_job = rehearse if rehearse else world
+    if rehearse:
+        total_cells = float(N)                   # ONE rank ran: the line reports that rank's rate, not a W-GPU rate
+    value = total_cells / 512 ** 3 * a.steps / elapsed
+    strong = a.scaling == 'strong' and ranks_in_job > 1
+    mask_txt = 'all-solid mask' if a.mask == 'box' else \
+        'ellipsoid mask (semi-axes 0.47 / 0.49 / 0.48 of the box, %.1f %% of this rank\'s cells in the mask)' % (100.0 * mask.mean())
     line = dict(
         metric='adi_steps_per_sec_512cubed_fp64', value=round(value, 3),
         unit='steps/s (512^3-cell equivalent, all GPUs)', n_gpus=world, steps=a.steps, warmup=a.warmup,
-        ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling='weak', vs_baseline=None,
-        dtype='f64', data='synthetic',
-        config=dict(workload='%dx%dx%d fp64 Cartesian, Robin h=500 all faces, theta=0.5, cfl=200, all-solid mask'
-                             % (world * n, n, n),
-                    cells_per_gpu=N, decomposition=('slabs along memory axis 0' if multi else 'none'),
+        ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling=('strong' if strong else 'weak'),
+        vs_baseline=None, dtype='f64', data='synthetic',
+        config=dict(workload='%dx%dx%d fp64 Cartesian, Robin h=500 all faces, theta=0.5, cfl=200, %s'
+                             % (nxg if multi else n, n, n, mask_txt),
+                    cells_per_gpu=N, planes_per_gpu=nxl,
+                    decomposition=('slabs along memory axis 0' if multi else 'none'),
                     sweep_variant={0: 'general', 1: 'no_dir', 2: 'no_q', 3: 'lean'}[variant]),
-        cell_updates_per_s=round(world * N * a.steps / elapsed, 1),
+        cell_updates_per_s=round(total_cells * a.steps / elapsed, 1),
         step_achieved_gbs=round(sum(bytes_per_cell.values()) * N / (ms_per_step * 1e-3) / 1e9, 1),
         **({'comm_overlap': dict(enabled=overlap_on, selfcheck_rel_diff=overlap_err,
                                  axis0_interface=stepper.axis0_mode,
-                                 pass_a=('dots_in_explicit' if (stepper._a0 or {}).get('dots') else
-                                         ('fused' if (stepper._a0 or {}).get('fused') else 'separate')))} if multi else {}),
+                                 pass_a=stepper.pass_a_form)} if multi else {}),
         **({'force_dist': 'slab code path over a single-rank RCCL process group' + (': halo / interface exchanges are RCCL '
                            'send/recv to self on the side stream' if rehearse else ' (plumbing check)')} if force_dist else {}),
-        **({'rehearsal': 'ONE GPU running the code path of rank %d of %d with a loopback communicator: per-rank compute '
-                         'time without wire time, not a %d-GPU measurement' % (rehearse // 2, rehearse, rehearse)}
+        **({'rehearsal': 'ONE GPU running the code path of rank %d of %d (%s scaling, %d planes) with a loopback '
+                         'communicator: per-rank compute time without wire time, not a %d-GPU measurement; `value` is this '
+                         'one rank\'s rate' % (rehearse // 2, rehearse, a.scaling, nxl, rehearse)}
            if rehearse else {}),
         roofline=dict(bound='hbm', kernel=dom, achieved=kernels[dom]['achieved_gbs'], peak=HBM_PEAK_GBS,
                       unit='GB/s', frac=kernels[dom]['frac'], traffic=traffic),
@@ -401,7 +529,31 @@ def main():
                                           target_frac=0.60,
                                           lean_sparse_variant_in_step=kernels.get('sweep_axis2_contig'))
     if not multi and not a.no_cpu:
-        st, mt = cpu_baseline(a.cpu_n)
+        # parity of the very kernels that were timed: PARITY_STEPS steps of the timed stepper from T0 (or, with --cpu-n,
+        # of the same workload at that edge) against the single-thread oracle leg started from the same host array
+        PARITY_STEPS = 3
+        cn = a.cpu_n
+        if cn == n:
+            Tp, pm, T0c = T_start, mask, T0_host
+            pstep = stepper
+        else:
+            pm = make_mask(a.mask, (cn, cn, cn))
+            T0c = np.random.default_rng(1).uniform(20.0, 1000.0, (cn, cn, cn))
+            g2 = adi.Grid3D(cn, cn, cn, dx, pm)
+            pstep = adi.StagedStepper(g2, mat, prm, adi.precompute_coeff_packs_unified(g2, mat, robin_h=500.0), Tinf)
+            Tp = adi.to_device(T0c)
+        for _ in range(PARITY_STEPS):
+            Tp = pstep.step(Tp)
+        got = Tp.get()
+        del Tp, T, T_start
+        torch.cuda.empty_cache()
+        st, mt, want = cpu_baseline(cn, pm, T0c, steps_1t=PARITY_STEPS)
+        den = float(np.abs(want).max())
+        line['parity_rel_linf'] = float(np.abs(got - want).max() / (den if den > 0 else 1.0))
+        line['parity'] = dict(rel_linf=line['parity_rel_linf'], bar=1e-10, steps=PARITY_STEPS, cells='%d^3' % cn,
+                              against='oracle/adi_oracle.c, 1 thread, same T0 (NumPy default_rng(1)) and mask',
+                              stepper='the StagedStepper that ran the timed loop' if cn == n else
+                                      'a StagedStepper of the same workload at the --cpu-n edge')
         line['cpu_baseline'] = st
         line['cpu_baseline_all_cores'] = mt
     emit(json.dumps(line))

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 and 3 over gloo: the slab decomposition (halo exchange, pass-A condensation,
+"""CPU, world_size 2, 3, 4 and 8 over gloo: the slab decomposition (halo exchange, pass-A condensation,
 all-gather, interface solve, pass-B injection) reproduces the single-domain oracle step."""
 import os
 import socket
@@ -33,8 +33,22 @@ def _decay_case(nx):
                 nsteps=3, births=None)
 
 
+def _stiff_case(nx):
+    """the bench's time step (cfl 200, theta 0.5: the coupling decays by 0.905 per row) on thin slabs: nothing has
+    decayed across a slab, so every world size > 2 must take the all-gather ('exact') interface solve -- the form of
+    BASELINE.json configs[2] (512^3 strong-split over 8 GPUs, 64 planes each)"""
+    c = _decay_case(nx)
+    alpha = c['mat']['k'] / (c['mat']['rho'] * c['mat']['cp'])
+    c.update(dt=200.0 * c['dx'] ** 2 / alpha, neumann={'x-': 1e5, 'x+': 2e5}, nsteps=2)
+    return c
+
+
 def _case(name):
-    return _decay_case(int(name.split(':')[1])) if name.startswith('decay:') else cases.cart_case(name)
+    if name.startswith('decay:'):
+        return _decay_case(int(name.split(':')[1]))
+    if name.startswith('stiff:'):
+        return _stiff_case(int(name.split(':')[1]))
+    return cases.cart_case(name)
 
 
 def _worker(rank, world, port, case_name, sizes, nsteps, q, opts=None):
@@ -139,6 +153,32 @@ def test_neighbour_only_interface_matches_single_domain(world, nx, opts, mode):
     assert modes == {mode}, modes
     want = run_cart_case(orc, c)['T_final']
     assert rel_linf(got, want) <= 1e-13, rel_linf(got, want)
+
+
+@pytest.mark.parametrize('world,name,sizes,opts,mode', [
+    (4, 'decay:256', [64] * 4, dict(prefetch=True), 'window'),
+    (4, 'decay:254', [64, 62, 64, 64], dict(prefetch=True), 'slab'),                 # one thinner slab: all take 'slab'
+    (4, 'decay:254', [64, 62, 64, 64], dict(prefetch=True, allow_dots=False, allow_fused=False), 'slab'),
+    (4, 'stiff:64', [16] * 4, dict(prefetch=True), 'exact'),
+    (4, 'stiff:62', [16, 14, 16, 16], dict(prefetch=True, allow_dots=False), 'exact'),
+    (8, 'decay:512', [64] * 8, dict(prefetch=True), 'window'),
+    (8, 'decay:194', [24, 24, 26, 24, 24, 24, 24, 24], dict(prefetch=True), 'slab'),
+    (8, 'decay:194', [24, 24, 26, 24, 24, 24, 24, 24], dict(prefetch=True, force_exact=True), 'exact'),
+    (8, 'stiff:64', [8] * 8, dict(prefetch=True), 'exact'),                          # the strong-scaling shape
+    (8, 'stiff:66', [8, 8, 8, 10, 8, 8, 8, 8], dict(prefetch=True, allow_dots=False, allow_fused=False), 'exact'),
+])
+def test_world_4_and_8_every_interface_form(world, name, sizes, opts, mode):
+    """the sizes the driver's scaling run uses (4 and 8 ranks), even and uneven slabs, every interface form with the
+    halo prefetch on: collectively agreed form, result = the single-domain oracle step to rounding"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import adi_oracle as orc
+    from helpers import run_cart_case, rel_linf
+    c = _case(name)
+    assert sum(sizes) == c['shape'][0] and len(sizes) == world
+    got, modes = _run_world(world, name, sizes, c['nsteps'], opts)
+    assert modes == {mode}, modes
+    want = run_cart_case(orc, c)['T_final']
+    assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
 
 
 def test_uneven_slabs_agree_on_one_interface_form():
