@@ -35,6 +35,7 @@ c_void_pp = ctypes.POINTER(c_void_p)
 # every exported symbol of include/adi_hip.h: name -> (restype, argtypes)
 SIGNATURES = {
     'adi_abi_version': (c_int, []),
+    'adi_build_stamp': (ctypes.c_char_p, []),
     'adi_last_error': (ctypes.c_char_p, []),
     'adi_device_count': (c_int, [c_int_p]),
     'adi_device_info': (c_int, [c_int, ctypes.c_char_p, c_int_p, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),

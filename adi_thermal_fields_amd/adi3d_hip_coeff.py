@@ -27,6 +27,7 @@ mask (and its neighbour-flags digest) is refreshed on every `grid.mask = ...` as
 precompute_coeff_packs_unified(grid, ...) call, which is the documented synchronisation point.
 """
 import ctypes
+import itertools
 
 import numpy as np
 import torch
@@ -38,6 +39,12 @@ __all__ = ['Grid3D', 'Material', 'Params', 'AxisCoeffPack', 'exposed_mask', 'pre
            'adi_step_hip_coeff', 'adi_step_numba_coeff', 'adi_step_gpu_coeff', 'DeviceField', 'to_device',
            'adi_explicit_rhs', 'adi_sweep_axis', 'StagedStepper', 'Layout', 'apply_surface_impulse_Q',
            'exposed_faces_per_layer', 'count_exposed_faces', 'perimeter_ratio', 'birth_planes', 'BirthPacks']
+
+
+# Mask versions come from ONE process-wide counter: a pack remembers the version of the mask it was built for, and a
+# version is never shared by two grids (a per-grid counter starting at 0 let packs of grid A pass for fresh on a
+# same-shape grid B and inherit A's no-fallback promise).
+_MASK_VERSIONS = itertools.count(1)
 
 
 def _device():
@@ -219,7 +226,7 @@ class Grid3D:
         self._d_flags = None
         self._all_solid = None
         self._scratch = None
-        self.mask_version = 0
+        self.mask_version = next(_MASK_VERSIONS)
         self.mask = np.asarray(mask).astype(np.bool_, copy=True, order='C')
 
     @property
@@ -252,7 +259,7 @@ class Grid3D:
         k_end = self.nz if k_end is None else k_end
         check(lib.adi_build_nbr_flags_planes(_p(self._d_mask), self.nx, self.ny, self.nz, self.sx, _p(self._d_flags),
                                              int(k_begin), int(k_end), _stream()))
-        self.mask_version += 1
+        self.mask_version = next(_MASK_VERSIONS)
         self._all_solid = None
 
     @property
@@ -286,7 +293,13 @@ class Grid3D:
         if getattr(self, '_device_mask', False) and self._mask is None:
             return self._d_mask
         self._device_mask = False
-        self._d_mask = self.layout.to_layout(self._mask, torch.uint8)
+        new = self.layout.to_layout(self._mask, torch.uint8)
+        if self._d_mask is not None and self._d_flags is not None and tuple(new.shape) == tuple(self._d_mask.shape) \
+                and torch.equal(new, self._d_mask):
+            # the same mask again (a second precompute_coeff_packs_unified on an unchanged grid: Dirichlet-vs-Robin
+            # comparisons, packs rebuilt with another h): flags and version stand, packs built earlier stay fresh
+            return self._d_mask
+        self._d_mask = new
         self._rebuild_flags()
         self._all_solid = bool(np.asarray(self._mask).all())     # hint for the kernels: no surface inside the box
         return self._d_mask
@@ -552,6 +565,10 @@ class _NoFallback:
         st += 1                                   # uses of this configuration so far
         if st >= self.LEARN_AFTER and not torch.cuda.is_current_stream_capturing():
             st = int(self.work[:4].view(torch.int32)[0].item()) == 0
+        if self.key not in self.cache:            # a new configuration: entries of older mask versions are dead (a
+            cur = self.key[4]                     # layer-birth run would otherwise add three keys per birth for good)
+            for k in [k for k in self.cache if k[4] != cur]:
+                del self.cache[k]
         self.cache[self.key] = st
 
 

@@ -159,6 +159,8 @@ class StagedCylStepper:
             check(lib.adi_cyl_sweep(self.plan.handle, ax, _p(a), _p(b), None, None, 0.0, 0.0, _stream()))
             if events is not None:
                 events[ax + 1].record()
+                if ax == 0 and g.nphi == 1:
+                    events[2].record()         # no phi sweep (phi_solve_spectral copies, :319-320): an empty interval
         return DeviceField(out)
 
     def _step_into(self, t, out):

@@ -203,6 +203,20 @@ static int step_impl(const double *d_T_in, double *d_T_out, double *d_tmp_a, dou
     const double gam = kappa * dt / (dx * dx);
     const double *q0 = d_qflux ? d_qflux[0] : nullptr, *q1 = d_qflux ? d_qflux[1] : nullptr, *q2 = d_qflux ? d_qflux[2] : nullptr;
     int rc;
+    // h_queued: a sweep that runs no FAST kernel (short lines, dense packs, a fused sweep the FAST kernel declines) never
+    // touches the queue word, and for lines beyond kMaxFastLine the workspace holds c' / d' doubles: the word is zeroed
+    // on the stream before every sweep and the long-line case reports 0 without reading it
+    const int nn[3] = {nx, ny, nz};
+    auto arm = [&](int axis) {
+        if (h_queued != nullptr && nn[axis] <= kMaxFastLine)
+            (void)hipMemsetAsync(d_work, 0, sizeof(unsigned), as_stream(stream));
+    };
+    auto report = [&](int axis) {
+        if (h_queued == nullptr) return;
+        if (nn[axis] > kMaxFastLine) { h_queued[axis] = 0u; return; }
+        (void)hipMemcpyAsync(h_queued + axis, d_work, sizeof(unsigned), hipMemcpyDeviceToHost, as_stream(stream));
+    };
+    arm(0);
     if (adi_explicit_fused_supported(nx, ny, nz, plane_stride, 0)) {
         // stages 1+2 in one pass: R0 is evaluated inside the loads of the axis-0 sweep
         const long sxe = plane_stride ? plane_stride : (long)ny * nz;
@@ -215,13 +229,12 @@ static int step_impl(const double *d_T_in, double *d_T_out, double *d_tmp_a, dou
         rc = adi_sweep(0, variant, d_tmp_a, d_flags, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_b, nullptr, nullptr, d_work, work_bytes, stream);
     }
     if (rc) return rc;
-    auto report = [&](int axis) {
-        if (h_queued != nullptr) (void)hipMemcpyAsync(h_queued + axis, d_work, sizeof(unsigned), hipMemcpyDeviceToHost, as_stream(stream));
-    };
     report(0);
+    arm(1);
     rc = adi_sweep(1, variant, d_tmp_b, d_flags, d_coeff[1], d_dir_mask, d_dir_val, q1, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_a, nullptr, nullptr, d_work, work_bytes, stream);
     if (rc) return rc;
     report(1);
+    arm(2);
     rc = adi_sweep(2, variant, d_tmp_a, d_flags, d_coeff[2], d_dir_mask, d_dir_val, q2, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_T_out, nullptr, nullptr, d_work, work_bytes, stream);
     if (rc) return rc;
     report(2);

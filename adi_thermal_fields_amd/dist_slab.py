@@ -220,7 +220,7 @@ class HipEngine:
         """precompute_coeff_packs_unified on the extended slab; returns packs whose arrays are extended too."""
         g = self.hip.Grid3D.__new__(self.hip.Grid3D)
         g.nx, g.ny, g.nz, g.dx, g.layout = L.nx, L.ny, L.nz, float(dx), L
-        g._mask, g._d_mask, g._d_flags, g._scratch, g.mask_version = None, mask_ext, flags_ext, None, 0
+        g._mask, g._d_mask, g._d_flags, g._scratch, g.mask_version = None, mask_ext, flags_ext, None, next(self.hip._MASK_VERSIONS)
         g.sync_mask = lambda: mask_ext            # the device mask (with halos) is authoritative here
         return self.hip.precompute_coeff_packs_unified(g, mat, dir_mask=dir_mask, dir_value=dir_value,
                                                        neumann=neumann, robin_h=robin_h)

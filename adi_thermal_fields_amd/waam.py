@@ -14,7 +14,8 @@ import math
 
 import numpy as np
 
-__all__ = ['synthetic_head_mask', 'plan_layers', 'birth_times', 'run_layer_birth', 'run_single_track']
+__all__ = ['synthetic_head_mask', 'plan_layers', 'birth_times', 'run_layer_birth', 'run_single_track',
+           'run_layer_birth_slab', 'run_single_track_slab']
 
 
 def synthetic_head_mask(nx, ny, nz):
@@ -268,3 +269,44 @@ def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, 
         if on_frame is not None and any(abs(te - to) <= 1e-12 for to in times_out):
             on_frame(t_now, np.array(st.local_numpy(T)), mask_act[i0:i1].copy())
     return np.array(st.local_numpy(T)), nsteps
+
+
+def run_single_track_slab(comm, i0, i1, plate_mask, track_box, dx, mat, params_cls, h, Tinf, T_track, theta, dt, t_step,
+                          engine=None):
+    """The moving deposit of single_track_on_plate.py:150-177 on ONE RANK of a slab decomposition (planes [i0, i1) of
+    memory axis 0; BASELINE.json configs[4]: "layer-birth + moving source, 4 GPUs").  The track box spans planes
+    [x0, x1) of the SHARDED axis, so a new column lands on every rank whose slab meets that range: those ranks switch
+    the column's cells on in their part of the mask and set them to T_track (:159-160, :166), every rank then rebuilds
+    flags and packs for its slab -- SlabStepper.set_mask: mask halo exchange (a column next to a slab boundary changes the
+    neighbour's halo coupling bits), flags, packs (:163) -- and takes the n_sub sub-steps of the column (:168-176).
+    Every rank keeps the full host mask for bookkeeping (1 bit of information per cell), as run_layer_birth_slab does.
+    Returns the local field as NumPy."""
+    from . import dist_slab
+    x0, x1, z0, z1, ncol = track_box
+    nx, ny, nz = plate_mask.shape
+    mask = np.array(plate_mask, dtype=bool)
+    params = params_cls(dt=dt, theta=theta)
+    robin = {f: h for f in ('x-', 'x+', 'y-', 'y+', 'z-', 'z+')}
+    st = dist_slab.SlabStepper(mask[i0:i1], dx, mat, params, Tinf, robin_h=robin, comm=comm, engine=engine)
+    T = np.full((i1 - i0, ny, nz), float(Tinf), dtype=np.float64)
+    on_device = getattr(st.engine.device, 'type', 'cpu') == 'cuda'
+    if on_device:
+        import torch
+        T = torch.from_numpy(T).to(st.engine.device)
+    lx0, lx1 = max(x0, i0) - i0, min(x1, i1) - i0            # the track box inside this slab (empty when lx0 >= lx1)
+    for yi in range(ncol):
+        mask[x0:x1, yi:yi + 1, z0:z1] = True
+        st.set_mask(mask[i0:i1])                               # collective: every rank, whether the column touches it or not
+        if lx0 < lx1:
+            if on_device:
+                T[lx0:lx1, yi:yi + 1, z0:z1] = T_track         # in place: the last sub-step sent no halo ahead
+            else:
+                Tl = np.array(st.local_numpy(T))
+                Tl[lx0:lx1, yi:yi + 1, z0:z1] = T_track
+                T = Tl
+        n_sub = max(1, int(math.ceil(t_step / dt)))
+        params.dt = t_step / n_sub
+        for s_ in range(n_sub):
+            T = st.step(T, prefetch_halo=(s_ + 1 < n_sub))
+        params.dt = dt
+    return np.array(st.local_numpy(T))

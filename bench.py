@@ -301,23 +301,19 @@ def main_cyl(a):
 
 
 def so_stamp():
-    """identity of the built library the numbers come from (first 16 hex digits of its SHA-256)"""
-    import hashlib
-    p = os.path.join(ROOT, 'adi_thermal_fields_amd', 'csrc', 'libadi_hip.so')
-    h = hashlib.sha256()
-    with open(p, 'rb') as f:
-        for blk in iter(lambda: f.read(1 << 20), b''):
-            h.update(blk)
-    return h.hexdigest()[:16]
+    """identity of the built library the numbers come from: adi_build_stamp(), a hash of its sources and compile flags
+    that does not depend on where the tree was built"""
+    from adi_thermal_fields_amd import _lib
+    return _lib.lib.adi_build_stamp().decode()
 
 
 def measured_traffic(kernel, config='cart'):
     """HBM bytes per launch of `kernel` from the PMC passes kept in profiles/pmc_traffic.json -- only when that file was
-    produced with THIS build of the library (it carries the library's hash); otherwise null"""
+    produced with THIS build of the library (it carries the library's stamp); otherwise null"""
     tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         d = json.load(open(tp))
-        if d.get('library_sha256_16') != so_stamp():
+        if d.get('library_stamp') != so_stamp():
             return None
         return (d.get(config) or {}).get(kernel)
     except Exception:

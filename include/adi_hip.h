@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 10
+#define ADI_ABI_VERSION 11
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -53,6 +53,10 @@ extern "C" {
 #define ADI_SWEEP_LEAN      3   /* neither:            in, mask, coeff -> out : 25 B/cell */
 
 int         adi_abi_version(void);
+/* identity of this build: 16 hex digits of the SHA-256 over the library's sources and compile flags (independent of the
+ * directory it was built in); profiles/pmc_traffic.json is stamped with it and bench.py quotes measured HBM traffic only
+ * for a library that reports the same stamp.  "unstamped" for a library not built by adi_thermal_fields_amd/build.py. */
+const char *adi_build_stamp(void);
 const char *adi_last_error(void);
 int         adi_device_count(int *count);
 /* name: caller buffer of >= 256 bytes; cu_count / hbm_bytes / lds_per_cu may be NULL */

@@ -7,7 +7,7 @@ gfx950 correction from the guide: FETCH_SIZE reports 1/2 of the bytes of a wide 
 exact.  Both counters are in KiB.
 
     python scripts/pmc_summary.py CART_FETCH_DIR CART_WRITE_DIR CYL_FETCH_DIR CYL_WRITE_DIR OUT.json"""
-import collections, csv, glob, hashlib, json, os, sys
+import collections, csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -32,11 +32,10 @@ def targs(k):
 
 
 def so_stamp():
-    h = hashlib.sha256()
-    with open(os.path.join(ROOT, 'adi_thermal_fields_amd', 'csrc', 'libadi_hip.so'), 'rb') as f:
-        for blk in iter(lambda: f.read(1 << 20), b''):
-            h.update(blk)
-    return h.hexdigest()[:16]
+    """adi_build_stamp() of the library in the tree: a hash of its sources and flags, independent of the build directory"""
+    sys.path.insert(0, ROOT)
+    from adi_thermal_fields_amd import _lib
+    return _lib.lib.adi_build_stamp().decode()
 
 
 cart = kernels(sys.argv[1], sys.argv[2])
@@ -54,7 +53,7 @@ lean = lambda a: len(a) >= 4 and not (a[1] == 'true' and a[2] == 'true')
 out = dict(
     note='HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of wide reads); a sweep = its FAST '
          'kernel + the GENERAL kernel on the queued units; keys are bench.py stage names',
-    library_sha256_16=so_stamp(),
+    library_stamp=so_stamp(),
     cart={'explicit+sweep_axis0': pick(cart, 'k_sweep_strided', lambda a: lean(a) and a[3] == 'true'),
           'sweep_axis1': pick(cart, 'k_sweep_strided', lambda a: lean(a) and a[3] == 'false'),
           'sweep_axis2_contig': pick(cart, 'k_sweep_contig', lambda a: len(a) >= 4 and not (a[2] == 'true' and a[3] == 'true'))},

@@ -1,7 +1,10 @@
 """GPU: BASELINE.json's full-size configurations.
-config 2 (256^3 Robin, 20 steps) is checked against the CPU oracle directly (OpenMP build of the same arithmetic,
-bit-identical to the serial oracle); 512^3 is checked through size-independent properties of the scheme
-(ambient fixed point, linearity of the step in (T, Tinf), mirror symmetry), since the oracle would take minutes."""
+config 2 (256^3 Robin, 20 steps) and the 512^3 headline workload (the very stepper bench.py times: 16 rows per lane,
+padded 2 MiB planes, fused explicit + axis-0 kernel, no-fallback promise) are checked against the CPU oracle directly
+(OpenMP build of the same arithmetic, bit-identical to the serial oracle: about 1.5 s per 512^3 step on the GPU box's
+host cores), 512^3 also with a curved solid and every array of the general pack live; on top of that 512^3 is checked
+through size-independent properties of the scheme (ambient fixed point, linearity of the step in (T, Tinf), mirror
+symmetry, maximum principle)."""
 import numpy as np
 import pytest
 
@@ -74,6 +77,76 @@ def test_config2_256_disk_dirichlet_neumann_general_pack_vs_oracle():
     assert np.all(got[dm] == 20.0)                                        # Dirichlet cells hold their value
     err = rel_linf(got, want)
     assert err <= 1e-10, err
+
+
+def test_512_bench_workload_3_steps_vs_oracle():
+    """The timed workload of bench.py itself (adi3d_numba_coeff.py:290-302 at 512^3: all-solid box, Robin h = 500 on all
+    faces, cfl 200, theta 0.5) through the StagedStepper bench.py uses -- FAST fused explicit + axis-0 kernel with 16 rows
+    per thread on 2 MiB-pitch padded planes, the two FAST sweeps, and the no-fallback promise learnt on the third step --
+    3 steps WITHOUT the promise and 3 steps WITH it from the same T0, both against the OpenMP oracle: <= 1e-10."""
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from oracle import adi_oracle as orc
+    n = 512
+    grid, mat, prm, packs = _setup(hip, n)
+    assert grid.layout.sx > n * n                      # padded planes
+    T0 = np.random.default_rng(1).uniform(20.0, 1000.0, (n, n, n))
+    st = hip.StagedStepper(grid, mat, prm, packs, 20.0)
+    assert st.fused and st.stage_names[0] == 'explicit+sweep_axis0'
+    T = hip.to_device(T0)
+    for _ in range(3):
+        T = st.step(T)
+    first = T.get()
+    T = hip.to_device(T0)
+    for _ in range(2):                                 # five steps of the configuration have run: the promise is learnt
+        T = st.step(T)
+    nofb = [v for p in packs for v in getattr(p, '_nofb', {}).values()]
+    assert len(nofb) == 3 and all(v is True for v in nofb), nofb
+    T = hip.to_device(T0)
+    for _ in range(3):
+        T = st.step(T)
+    second = T.get()
+    del T
+    og = orc.Grid3D(n, n, n, grid.dx, np.ones((n, n, n), bool))
+    om = orc.Material(**STEEL); op = orc.Params(prm.dt, prm.theta)
+    opacks = orc.precompute_coeff_packs_unified(og, om, robin_h=500.0, _share=True)
+    want = orc.adi_run(T0, og, om, op, opacks, Tinf=20.0, nsteps=3, omp=True)
+    assert rel_linf(first, want) <= 1e-10, rel_linf(first, want)
+    assert np.array_equal(first, second)               # the promise changes which launches run, not one bit of the result
+
+
+def test_512_ellipsoid_general_pack_2_steps_vs_oracle():
+    """512^3 box holding a curved solid (ellipsoid, semi-axes 0.47 / 0.49 / 0.48 of the box) with every array of the
+    general pack live: Dirichlet cells on one plane through the solid, Neumann flux on the exposed z- faces, Robin on the
+    others.  Surface segments (TAIL / HEAD) in all three FAST kernels, Dirichlet tiles through the GENERAL kernels,
+    2 steps against the OpenMP oracle: <= 1e-10; off-mask cells untouched, Dirichlet cells at their value."""
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from oracle import adi_oracle as orc
+    n = 512
+    dx = 5e-4
+    c = [((np.arange(n) + 0.5) / n - 0.5) / a for a in (0.47, 0.49, 0.48)]
+    mask = (c[0][:, None, None] ** 2 + c[1][None, :, None] ** 2 + c[2][None, None, :] ** 2) <= 1.0
+    dm = np.zeros((n, n, n), bool); dm[:, :, 96] = mask[:, :, 96]
+    kw = dict(dir_mask=dm, dir_value=20.0, neumann={'z-': 2e6},
+              robin_h={'x-': 500.0, 'x+': 500.0, 'y-': 500.0, 'y+': 500.0, 'z+': 300.0})
+    T0 = np.random.default_rng(2).uniform(20.0, 1000.0, (n, n, n))
+    alpha = STEEL['k'] / (STEEL['rho'] * STEEL['cp'])
+    dt = 200.0 * dx * dx / alpha
+    grid = hip.Grid3D(n, n, n, dx, mask)
+    mat = hip.Material(**STEEL); prm = hip.Params(dt, 0.5)
+    packs = hip.precompute_coeff_packs_unified(grid, mat, **kw)
+    assert packs[2].variant == 0 and packs[0].has_q is True
+    T = hip.to_device(T0)
+    for _ in range(2):
+        T = hip.adi_step_hip_coeff(T, grid, mat, prm, packs, Tinf=20.0)
+    got = T.get()
+    del T, packs, grid
+    og = orc.Grid3D(n, n, n, dx, mask)
+    om = orc.Material(**STEEL); op = orc.Params(dt, 0.5)
+    opacks = orc.precompute_coeff_packs_unified(og, om, _share=True, **kw)
+    want = orc.adi_run(T0, og, om, op, opacks, Tinf=20.0, nsteps=2, omp=True)
+    assert np.array_equal(got[~mask], T0[~mask])
+    assert np.all(got[dm] == 20.0)
+    assert rel_linf(got, want) <= 1e-10, rel_linf(got, want)
 
 
 def test_512_properties():

@@ -116,6 +116,60 @@ def test_stale_packs_after_mask_rebind_follow_the_reference(hip):
     assert rel_linf(outs[0], outs[1]) <= TOL, rel_linf(outs[0], outs[1])
 
 
+def test_packs_of_one_grid_on_another_grid_follow_the_reference(hip):
+    """Packs built on grid A, stepped on a same-shape grid B with a DIFFERENT mask: the reference reads coeff at every
+    in-mask cell of B (adi3d_numba_coeff.py:150-162), so A's sparsity pattern must not be applied to B's flags, and the
+    no-fallback promise A's packs learnt on A must not travel either (under a false promise the FAST kernel would leave
+    tiles unwritten).  Mask versions come from one process-wide counter, so no two grids ever share one."""
+    from oracle import adi_oracle as orc
+    shape = (256, 16, 64)
+    rng = np.random.default_rng(17)
+    mask_a = np.ones(shape, bool)
+    mask_b = rng.random(shape) > 0.06                                     # voids everywhere: surface units get queued
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    T0 = rng.uniform(20.0, 900.0, shape)
+    outs = []
+    for api in (hip, orc):
+        ga = api.Grid3D(*shape, dx, mask_a)
+        gb = api.Grid3D(*shape, dx, mask_b)
+        mat = api.Material(7800.0, 490.0, 54.0)
+        prm = api.Params(150.0 * dx * dx / alpha, 0.5)
+        packs = api.precompute_coeff_packs_unified(ga, mat, robin_h=350.0)
+        step = getattr(api, 'adi_step_hip_coeff', None) or api.adi_step_numba_coeff
+        if api is hip:
+            assert ga.mask_version != gb.mask_version
+            W = hip.to_device(T0)
+            for _ in range(4):                                            # A learns the promise (all-solid: nothing queued)
+                W = step(W, ga, mat, prm, packs, Tinf=20.0)
+            assert all(v is True for p in packs for v in p._nofb.values())
+        T = np.array(T0)
+        for _ in range(2):
+            T = step(T, gb, mat, prm, packs, Tinf=20.0)
+        outs.append(T)
+    assert np.array_equal(outs[0][~mask_b], T0[~mask_b])
+    assert rel_linf(outs[0], outs[1]) <= TOL, rel_linf(outs[0], outs[1])
+
+
+def test_second_pack_set_on_an_unchanged_grid_keeps_the_first_fresh(hip):
+    """precompute_coeff_packs_unified re-uploads the mask every time (the documented synchronisation point); when the
+    mask has not changed the flags and the mask version stand, so packs built earlier (a Dirichlet-vs-Robin comparison,
+    packs rebuilt with another h) keep their sparse reads; an in-place change of the host mask is still picked up."""
+    c = cases.cart_case('long_line_70')
+    grid = hip.Grid3D(*c['shape'], c['dx'], c['mask'])
+    mat = hip.Material(**c['mat'])
+    p1 = hip.precompute_coeff_packs_unified(grid, mat, robin_h=300.0)
+    v1 = grid.mask_version
+    p2 = hip.precompute_coeff_packs_unified(grid, mat, robin_h=900.0)
+    assert grid.mask_version == v1
+    assert all(hip._sparse_arg(grid, p, False) & 1 for p in p1 + p2)
+    m = grid.mask
+    m[1, 1, 1] = not m[1, 1, 1]                                           # mutated in place, then the packs are rebuilt
+    p3 = hip.precompute_coeff_packs_unified(grid, mat, robin_h=300.0)
+    assert grid.mask_version != v1
+    assert not any(hip._sparse_arg(grid, p, False) & 1 for p in p1) and all(hip._sparse_arg(grid, p, False) & 1 for p in p3)
+
+
 @pytest.mark.parametrize('variant,dense', [(0, True), (0, False), (None, False)])
 def test_cart_stages_vs_golden(hip, variant, dense):
     """every stage alone, fed with the reference's own previous stage; variant 0 + dense forces the

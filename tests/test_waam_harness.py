@@ -95,6 +95,102 @@ def test_single_track_hip_matches_oracle():
     assert rel_linf(got, want) <= 1e-10, rel_linf(got, want)
 
 
+def _single_track_case():
+    """a plate of 5 planes along axis 2, a track of 12 columns along axis 1 on top of it whose box spans planes 5..19 of
+    the SHARDED axis: with slabs of 8 planes the deposit lands on ranks 0, 1 and 2, with its ends one plane inside rank 0
+    and rank 2 (so the neighbours' halo coupling bits change with every column)"""
+    shape = (24, 18, 12)
+    plate = np.zeros(shape, bool); plate[:, :, :5] = True
+    box = (5, 20, 5, 8, 12)
+    return shape, plate, box, (1e-3, STEEL, 25.0, 20.0, 1500.0, 0.5, 0.02, 0.05)
+
+
+@pytest.mark.gpu
+def test_single_track_on_slabs_matches_single_domain_and_oracle():
+    """configs[4] "moving source" on slabs (single_track_on_plate.py:157-177): 3 in-process ranks on one GPU (HIP engine)
+    against the single-domain HIP run of the same loop (<= 1e-11) and against the CPU oracle (<= 1e-10)"""
+    import threading
+    import torch
+    from oracle import adi_oracle as orc
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from adi_thermal_fields_amd import dist_slab, waam
+    shape, plate, box, rest = _single_track_case()
+    dx, _, h, Tinf, T_track, theta, dt, t_step = rest
+    one = waam.run_single_track(hip, plate, box, *rest)
+    want = waam.run_single_track(orc, plate, box, *rest)
+    for world, sizes in ((3, [8, 8, 8]), (4, [6, 6, 6, 6]), (2, [12, 12])):
+        comms = dist_slab.LocalComm.make(world)
+        parts, errs = [None] * world, []
+
+        def work(rank):
+            try:
+                torch.cuda.set_device(0)
+                i0 = sum(sizes[:rank]); i1 = i0 + sizes[rank]
+                parts[rank] = waam.run_single_track_slab(comms[rank], i0, i1, plate, box, dx, hip.Material(*STEEL), hip.Params,
+                                                         h, Tinf, T_track, theta, dt, t_step)
+            except Exception as e:
+                errs.append(e)
+                comms[rank].sh.barrier.abort()
+        ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=300)
+        if errs:
+            raise errs[0]
+        got = np.concatenate(parts, axis=0)
+        assert rel_linf(got, one) <= 1e-11, (world, rel_linf(got, one))
+        assert rel_linf(got, want) <= 1e-10, (world, rel_linf(got, want))
+        assert np.array_equal(got[~plate & (got == Tinf)], want[~plate & (got == Tinf)])
+
+
+def _track_worker(rank, world, port, sizes, q):
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from adi_thermal_fields_amd import dist_slab, waam
+        from cpu_engine import CpuEngine
+        from oracle import adi_oracle as orc
+        shape, plate, box, rest = _single_track_case()
+        dx, _, h, Tinf, T_track, theta, dt, t_step = rest
+        i0 = sum(sizes[:rank]); i1 = i0 + sizes[rank]
+        part = waam.run_single_track_slab(dist_slab.TorchDistComm(), i0, i1, plate, box, dx, orc.Material(*STEEL), orc.Params,
+                                          h, Tinf, T_track, theta, dt, t_step, engine=CpuEngine())
+        q.put((rank, part))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_track_on_slabs_gloo_matches_oracle():
+    """the same loop on CPU ranks over gloo (reference engine): the host logic of run_single_track_slab -- which ranks a
+    column lands on, the collective mask / pack rebuild, the sub-stepping -- against the single-domain oracle loop"""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import adi_oracle as orc
+    from adi_thermal_fields_amd import waam
+    shape, plate, box, rest = _single_track_case()
+    want = waam.run_single_track(orc, plate, box, *rest)
+    world, sizes = 3, [8, 8, 8]
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_track_worker, args=(r, world, port, sizes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got = np.concatenate([parts[r] for r in range(world)], axis=0)
+    assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
+
+
 @pytest.mark.gpu
 def test_layer_birth_on_slabs_matches_single_domain():
     """configs[4] structure: layer birth on a slab decomposition (3 in-process ranks on one GPU, HIP engine) against
