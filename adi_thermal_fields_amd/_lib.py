@@ -79,6 +79,11 @@ SIGNATURES = {
                                       c_double, c_double, c_long, c_long, c_void_p, c_void_p]),
     'adi_interface_solve': (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
     'adi_interface_pair': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    'adi_axis0_deferred_setup': (c_int, [c_int, c_double, c_double, c_double, c_void_p, c_double_p, c_int_p, c_void_p]),
+    'adi_interface_deferred': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_long, c_void_p, c_void_p, c_void_p]),
+    'adi_sweep_corrected': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'adi_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_pp, c_void_p, c_void_p,
                          c_void_pp, c_int, c_int, c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double,
                          c_double, c_double, c_double, c_void_p, c_size_t, c_void_p]),

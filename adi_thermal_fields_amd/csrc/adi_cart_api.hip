@@ -31,7 +31,8 @@ static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t 
                        const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
                        long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
                        const double *d_xlo, const double *d_xhi, void *d_work, size_t work_bytes, void *stream,
-                       const Fuse *fz)
+                       const Fuse *fz, const double *c_lo = nullptr, const double *c_hi = nullptr,
+                       const double *c_w = nullptr)
 {
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep: bad axis %d", axis);
     bool has_dir, has_q;
@@ -49,6 +50,12 @@ static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t 
     s.sparse = (sparse & 1) ? 1 : 0;
     s.box = (sparse & 2) ? 1 : 0;
     s.nofb = (sparse & 4) ? 1 : 0;
+    if (c_w != nullptr && (c_lo != nullptr || c_hi != nullptr)) {
+        // deferred interface correction (adi_sweep_corrected): the strided kernels of memory axis 1 add it to what they load
+        ADI_REQUIRE(axis == 1 && fz == nullptr && !d_xlo && !d_xhi, "adi_sweep_corrected: axis 1 sweeps only");
+        ADI_REQUIRE((long)ny * nz * 8 < 0x7fffffffL, "adi_sweep_corrected: plane of %ld cells is too large", (long)ny * nz);
+        s.c_lo = c_lo; s.c_hi = c_hi; s.c_w = c_w; s.c_n = nx; s.c_bytes = (unsigned)((long)ny * nz * 8);
+    }
     hipStream_t st = as_stream(stream);
     SweepArgs a;
     a.in = d_in; a.flags = d_flags; a.coeff = d_coeff;
@@ -81,6 +88,18 @@ int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags,
 {
     return sweep_entry(axis, variant, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
                        sparse, theta, gam, dt, Tinf, d_out, d_xlo, d_xhi, d_work, work_bytes, stream, nullptr);
+}
+
+int adi_sweep_corrected(int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
+                        const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
+                        long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
+                        const double *d_ulo, const double *d_uhi, const double *d_w, void *d_work, size_t work_bytes,
+                        void *stream)
+{
+    ADI_REQUIRE(d_w != nullptr || (d_ulo == nullptr && d_uhi == nullptr), "adi_sweep_corrected: interface values without weights");
+    return sweep_entry(1, variant, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
+                       sparse, theta, gam, dt, Tinf, d_out, nullptr, nullptr, d_work, work_bytes, stream, nullptr, d_ulo,
+                       d_uhi, d_w);
 }
 
 static Fuse make_fuse(int nx, int ny, int nz, long plane_stride, double dx, double dt, double kappa, double theta,

@@ -63,6 +63,14 @@ struct SweepScal {
     int nofb = 0; // promise (bit 2 of `sparse`): the FAST kernel takes every unit of this sweep -- the caller has seen the
                   //    unit queue of the same (mask, packs, variant, shape) come back empty; the queue reset and the GENERAL
                   //    launch behind the FAST kernel are skipped (3 + 3 launches of ~4.5 us and their gaps per step)
+    // Deferred interface correction of a slab decomposition (adi_sweep_corrected, strided axis 1 only): the value this
+    // sweep reads at (plane i, row j, column k) is  in + c_w[i] * c_lo[j*nz + k] + c_w[c_n - 1 - i] * c_hi[j*nz + k]
+    // -- the axis-0 sweep before it solved every line with zero boundary values, and by linearity the true solution
+    // differs from that by the two interface values of the line times the decaying homogeneous solutions c_w.
+    // c_lo / c_hi: dense (ny, nz) planes (null: no neighbour on that side); c_w: c_n weights, exactly 0 beyond their reach.
+    const double *c_lo = nullptr, *c_hi = nullptr, *c_w = nullptr;
+    int c_n = 0;
+    unsigned c_bytes = 0;   // bytes of a correction plane (the range of the buffer descriptors over c_lo / c_hi)
 };
 
 // cell is in the mask and lacks at least one in-mask neighbour along the sweep axis: the only cells where
@@ -395,6 +403,34 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned
     u32x2 v;
     v.x = (unsigned)__double2loint(x); v.y = (unsigned)__double2hiint(x);
     __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, ADI_STORE_AUX);
+}
+
+// Deferred interface correction (SweepScal::c_*): weights of the plane `to` this tile lies in (block-uniform, scalar
+// loads) and the correction of M rows of one line.  off8: byte offset of this thread's row 0 inside a correction plane,
+// st8: bytes between rows.  The planes are read through range-checked buffer descriptors, so the rows of a padding
+// segment (beyond the end of the line) read 0.  The loads are L2 hits: two planes re-read by every plane of the slab.
+__device__ __forceinline__ double2 corr_weights(const SweepScal &s, long to)
+{
+    double2 w = make_double2(0.0, 0.0);
+    if (s.c_w != nullptr) {
+        if (s.c_lo != nullptr) w.x = s.c_w[to];
+        if (s.c_hi != nullptr) w.y = s.c_w[s.c_n - 1 - to];
+    }
+    return w;
+}
+template <int M>
+__device__ __forceinline__ void corr_apply(const SweepScal &s, double2 w, unsigned off8, unsigned st8, double (&d)[M])
+{
+    if (w.x != 0.0) {
+        const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc((void *)s.c_lo, 0, (int)s.c_bytes, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.x, buf_load_f64(rL, off8, (unsigned)r * st8), d[r]);
+    }
+    if (w.y != 0.0) {
+        const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void *)s.c_hi, 0, (int)s.c_bytes, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.y, buf_load_f64(rH, off8, (unsigned)r * st8), d[r]);
+    }
 }
 
 template <int CTRL>

@@ -3,6 +3,8 @@
 // k_interface / k_interface_pair solve the reduced interface system; pass B is the ordinary sweep with the two boundary
 // values injected (adi_sweep_strided.hip).  No counterpart in the reference (single process); the per-line algebra is
 // thomas_solve's (adi3d_numba_coeff.py:121-130) block elimination.
+#include <vector>
+
 #include "adi_cart_host.hpp"
 #include "adi_strided_dev.hpp"
 
@@ -415,6 +417,35 @@ void condense_generic_lines(bool has_dir, bool has_q, const SweepArgs &a, const 
     else hipLaunchKernelGGL((k_condense_generic<false, false>), gl, block, 0, st, a.in, a.flags, a.coeff, nullptr, nullptr, nullptr, cond, nlines, g, inner_stride, s, list, line_begin, nsel);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K5c: interface values of the DEFERRED form.  Every rank has solved its part of every sharded-axis line with zero
+// boundary values: x0.  By linearity the solution of the whole line is, inside the slab,
+//     x[i] = x0[i] + xlo * w[i] + xhi * w[n-1-i],     w = theta*gamma * tridiag(-tg, 1+2tg, -tg)^-1 e_0,
+// with xlo / xhi the unknowns adjacent to the slab on the neighbouring ranks.  Where w has decayed below rounding
+// across a slab (the caller checks it, as for adi_interface_pair) the interface system splits into one 2 x 2 system per
+// boundary: with L the last unknown of the slab below, F the first unknown of this slab and om = w[0],
+//     L = x0_last(below) + om * F,    F = x0_first(mine) + om * L.
+// first / last: planes 0 and n-1 of this rank's x0; prev_last / next_first: the adjacent planes of the neighbours' x0
+// (null: no neighbour).  ulo = L of the boundary below, uhi = F of the boundary above; 0 where there is no neighbour.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_interface_deferred(const double *__restrict__ first, const double *__restrict__ last,
+                                                            const double *__restrict__ prev_last,
+                                                            const double *__restrict__ next_first, double om, double idet,
+                                                            long nlines, double *__restrict__ ulo, double *__restrict__ uhi)
+{
+    const long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlines) return;
+    double lo = 0.0, hi = 0.0;
+    if (prev_last != nullptr) {
+        const double gL = prev_last[l];
+        const double F = __builtin_fma(om, gL, first[l]) * idet;
+        lo = __builtin_fma(om, F, gL);
+    }
+    if (next_first != nullptr) hi = __builtin_fma(om, last[l], next_first[l]) * idet;
+    ulo[l] = lo;
+    uhi[l] = hi;
+}
+
 }  // namespace adi
 
 using namespace adi;
@@ -439,6 +470,48 @@ int adi_interface_pair(const double *d_my_lo, const double *d_my_hi, const doubl
     ADI_REQUIRE((!d_prev_hi || d_my_lo) && (!d_next_lo || d_my_hi), "adi_interface_pair: missing own window");
     hipLaunchKernelGGL(k_interface_pair, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, as_stream(stream), d_my_lo,
                        d_my_hi, d_prev_hi, d_next_lo, nlines, d_xlo, d_xhi);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+int adi_axis0_deferred_setup(int n, double theta, double gam, double tol, double *d_w, double *h_omega, int *h_reach,
+                             void *stream)
+{
+    ADI_REQUIRE(n >= 2 && d_w && h_omega && h_reach && tol >= 0.0, "adi_axis0_deferred_setup: bad argument");
+    // w = tg * tridiag(-tg, 1+2tg, -tg)^-1 e_0 (n x n): Thomas in long double; the closure of the far end does not
+    // matter where w has decayed there, which is the condition the caller tests (*h_reach < n)
+    const long double tg = (long double)theta * (long double)gam, b = 1.0L + 2.0L * tg;
+    std::vector<long double> cp(n), x(n);
+    std::vector<double> w(n);
+    long double piv = b;
+    cp[0] = -tg / piv; x[0] = tg / piv;
+    for (int i = 1; i < n; ++i) {
+        piv = b + tg * cp[i - 1];
+        cp[i] = -tg / piv;
+        x[i] = (tg * x[i - 1]) / piv;
+    }
+    for (int i = n - 2; i >= 0; --i) x[i] -= cp[i] * x[i + 1];
+    int reach = 0;
+    for (int i = 0; i < n; ++i) {
+        w[i] = (double)x[i];
+        if (w[i] > tol) reach = i + 1; else w[i] = 0.0;      // (w decreases monotonically: exactly 0 beyond its reach)
+    }
+    *h_omega = w[0];
+    *h_reach = reach;
+    ADI_HIP_TRY(hipMemcpyAsync(d_w, w.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, as_stream(stream)));
+    ADI_HIP_TRY(hipStreamSynchronize(as_stream(stream)));      // w lives on this stack frame
+    return ADI_OK;
+}
+
+int adi_interface_deferred(const double *d_first, const double *d_last, const double *d_prev_last,
+                           const double *d_next_first, double omega, long nlines, double *d_ulo, double *d_uhi,
+                           void *stream)
+{
+    ADI_REQUIRE(d_ulo && d_uhi && nlines > 0, "adi_interface_deferred: bad argument");
+    ADI_REQUIRE((!d_prev_last || d_first) && (!d_next_first || d_last), "adi_interface_deferred: missing own plane");
+    ADI_REQUIRE(omega >= 0.0 && omega < 1.0, "adi_interface_deferred: omega = %g is not a decaying weight", omega);
+    const double idet = 1.0 / (1.0 - omega * omega);
+    hipLaunchKernelGGL(k_interface_deferred, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       d_first, d_last, d_prev_last, d_next_first, omega, idet, nlines, d_ulo, d_uhi);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }

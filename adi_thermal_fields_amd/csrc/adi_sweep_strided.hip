@@ -67,6 +67,11 @@ __device__ __forceinline__ void strided_tile_general(
         }
         else
             load_segment_raw<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R, fz, bstrip);
+        if constexpr (!FUSE) {
+            // deferred interface correction of a slab decomposition (SweepScal::c_*): block-uniform, off in ordinary sweeps
+            if (s.c_w != nullptr)
+                corr_apply<M>(s, corr_weights(s, to), (voff + (unsigned)(ti * LINES)) * 8u, (unsigned)(g.stride * 8), R.vin);
+        }
 #pragma unroll
         for (int r = 0; r < M; ++r) {
             double ar, cr;
@@ -150,11 +155,15 @@ __global__ __launch_bounds__(256) void k_sweep_generic(
     const long base = o * g.outer_stride + kc * inner_stride;
     const int n = g.n;
     double cp = 0.0, dp = 0.0;
+    const double2 cw = corr_weights(s, o);            // deferred interface correction (SweepScal::c_*), off in ordinary sweeps
     for (int r = 0; r < n; ++r) {
         const long p = base + (long)r * g.stride;
         const unsigned f = flags[p];
         double a, b, c, d;
-        assemble_row<HAS_DIR, HAS_Q>(f & 1u, (f >> g.lbit) & 1u, (f >> (g.lbit + 1)) & 1u, HAS_DIR && dmask[p] != 0, in[p],
+        double vin = in[p];
+        if (cw.x != 0.0) vin = __builtin_fma(cw.x, s.c_lo[(long)r * g.stride + kc * inner_stride], vin);
+        if (cw.y != 0.0) vin = __builtin_fma(cw.y, s.c_hi[(long)r * g.stride + kc * inner_stride], vin);
+        assemble_row<HAS_DIR, HAS_Q>(f & 1u, (f >> g.lbit) & 1u, (f >> (g.lbit + 1)) & 1u, HAS_DIR && dmask[p] != 0, vin,
                                      coeff[p], HAS_DIR ? dval[p] : 0.0, HAS_Q ? qf[p] : 0.0, s, a, b, c, d);
         if (r == 0) { if (xlo != nullptr) d -= a * xlo[lid]; a = 0.0; }
         if (r == n - 1) { if (xhi != nullptr) d -= c * xhi[lid]; c = 0.0; }

@@ -293,9 +293,49 @@ class HipEngine:
     def sweep0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, t_out, xlo=None, xhi=None):
         h = self.hip
         w = self._workspace(L)
-        self.check(self.lib.adi_explicit_sweep0(*self._fused_args(variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa,
-                                                                  theta, Tinf),
-                                                h._p(t_out), h._p(xlo), h._p(xhi), h._p(w), w.numel(), h._stream()))
+        key, bit = self._promise('fused', 0, variant, L, flags, pack)
+        a = list(self._fused_args(variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf))
+        a[13] |= bit
+        self.check(self.lib.adi_explicit_sweep0(*a, h._p(t_out), h._p(xlo), h._p(xhi), h._p(w), w.numel(), h._stream()))
+        self._learn(key, w)
+
+    # deferred form of the sharded-axis sweep (include/adi_hip.h, ABI v12): every line solved with zero boundary values by
+    # the single-domain kernel, one plane to each neighbour, 2 x 2 interface systems, and the rank-two correction added by
+    # the axis-1 sweep to what it loads
+    def lines_all_uniform(self, Li, flags_int, dmask_int):
+        """every sharded-axis line of the slab is solid and free of Dirichlet cells (reads one int: synchronises)"""
+        h = self.hip
+        nl = Li.ny * Li.nz
+        cls = torch.empty(nl, dtype=torch.uint8, device=self.device)
+        lst = torch.empty(nl + 1, dtype=torch.int32, device=self.device)
+        self.check(self.lib.adi_axis0_classify(h._p(flags_int), h._p(dmask_int), Li.nx, Li.ny, Li.nz, Li.sx, h._p(cls),
+                                               h._p(lst), h._stream()))
+        return int(lst[0].item()) == 0
+
+    def deferred_setup(self, n, theta, gam, tol):
+        """-> dict(w: device weights with exact zeros beyond their reach, omega = w[0], reach)"""
+        h = self.hip
+        w = self.vec(n)
+        om, reach = ctypes.c_double(0.0), ctypes.c_int(0)
+        self.check(self.lib.adi_axis0_deferred_setup(n, theta, gam, tol, h._p(w), ctypes.byref(om), ctypes.byref(reach),
+                                                     h._stream()))
+        return dict(w=w, omega=om.value, reach=reach.value)
+
+    def interface_deferred(self, first, last, prev_last, next_first, omega, nlines, ulo, uhi):
+        h = self.hip
+        self.check(self.lib.adi_interface_deferred(h._p(first), h._p(last), h._p(prev_last), h._p(next_first), omega,
+                                                   nlines, h._p(ulo), h._p(uhi), h._stream()))
+
+    def sweep_corrected(self, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, ulo, uhi, w_corr):
+        """axis-1 sweep of t_in + w[i] * ulo + w[n-1-i] * uhi"""
+        h = self.hip
+        w = self._workspace(Li)
+        key, bit = self._promise('sweep', 1, variant, Li, flags, pack)
+        a = list(self._args(1, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf))
+        a[12] |= bit
+        self.check(self.lib.adi_sweep_corrected(*a[1:], h._p(t_out), h._p(ulo), h._p(uhi), h._p(w_corr), h._p(w), w.numel(),
+                                                h._stream()))
+        self._learn(key, w)
 
     def condense0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, cond, r0_out=None):
         """r0_out (optional, a view of the box in an array laid out like T_ext): also receives R0"""
@@ -392,6 +432,7 @@ class SlabStepper:
         self.fused = False
         self._keep_r0 = True                       # False: pass B re-evaluates the explicit stage instead of reading R0
         self._allow_dots = True                    # False: pass A as its own kernel (reads the slab a second time)
+        self._allow_deferred = True                # False: never the deferred form (zero-boundary solve + correction on load)
         self._send_g_only = True                   # False: every step exchanges the matrix parts of the interface too
         self._comm_stream, self._use_streams = None, False
         self._halo_ready, self._halo_event = None, None
@@ -457,6 +498,11 @@ class SlabStepper:
 
     @property
     def stage_names(self):
+        if self._a0 is not None and self._a0['mode'] == 'deferred':
+            a1 = 'interface+sweep_axis1_corrected'
+            if self._a0['fused']:
+                return ['halo+explicit+sweep_axis0_zero_boundary', a1, 'sweep_axis2_contig']
+            return ['halo+explicit', 'sweep_axis0_zero_boundary', a1, 'sweep_axis2_contig']
         if self._fused_now():
             return ['halo+explicit+sweep_axis0_distributed', 'sweep_axis1', 'sweep_axis2_contig']
         return ['halo+explicit', 'sweep_axis0_distributed', 'sweep_axis1', 'sweep_axis2_contig']
@@ -465,6 +511,8 @@ class SlabStepper:
     def pass_a_form(self):
         """how pass A of the sharded-axis sweep runs under the current plan (bench.py reports it)"""
         p = self._a0 or {}
+        if p.get('mode') == 'deferred':
+            return 'none (zero-boundary solve; planes 0 and n-1 of its result are the pass-A right-hand sides)'
         return 'dots_in_explicit' if p.get('dots') else ('fused' if p.get('fused') else 'separate')
 
     @property
@@ -472,6 +520,9 @@ class SlabStepper:
         """algorithmic HBM bytes per local cell of the stages (pass A re-reads the inputs of the rows it covers)"""
         bpc = self._bpc
         frac = 0.0
+        if self._a0 is not None and self._a0['mode'] == 'deferred':
+            # one pass per sweep; the two interface planes the axis-1 sweep re-reads are 2 * ny * nz values per slab
+            return [bpc[0], bpc[1], bpc[2]] if self._a0['fused'] else [self._explicit_bpc, bpc[0], bpc[1], bpc[2]]
         if self.world > 1:
             frac = 1.0 if (self._a0 is None or self._a0['mode'] != 'window') else min(1.0, 2.0 * self._a0['K'] / self.nxl)
             if self._a0 is not None and self._a0.get('dots'):
@@ -562,7 +613,7 @@ class SlabStepper:
         'slab' (the whole slab is its own window).  Collective: every rank calls it at the same step."""
         prm = self.params
         key = (float(prm.dt), float(prm.theta), self._mask_version, self._force_exact, self._no_overlap,
-               self._allow_fused, self._allow_window, self._keep_r0, self._allow_dots)
+               self._allow_fused, self._allow_window, self._keep_r0, self._allow_dots, self._allow_deferred)
         if self._a0_key == key:
             return self._a0
         E, v = self.engine, self.variant
@@ -588,6 +639,27 @@ class SlabStepper:
                            gam, prm.dt, self.Tinf, c)
                 worst = max(worst, float(c.view(6, nl)[4].abs().max()))
             return Lw, worst, bool(worst <= self.DECAY_TOL)          # NaN compares false -> not decayed
+        # Deferred form first (its eligibility costs one pass over the flags and a host-side solve): every sharded-axis
+        # line of every slab uniform -- solid, no Dirichlet cell -- and the homogeneous solution decayed across every slab.
+        dfr = None
+        if self._allow_deferred and not self._force_exact and hasattr(E, 'deferred_setup') and self.nxl >= 2:
+            dset = E.deferred_setup(self.nxl, prm.theta, gam, self.DECAY_TOL)
+            if dset['reach'] < self.nxl and E.lines_all_uniform(self.Lint, fl, pk[1]):
+                dfr = dset
+        dflag = E.vec(2)
+        dflag[0] = 1.0 if dfr is not None else 0.0
+        dflag[1] = 1.0 if (self._allow_fused and hasattr(E, 'sweep0_fused')
+                           and E.fused_supported(self.nxl, self.ny, self.nz, self.Lint.sx, False)) else 0.0
+        alld = E.vec(2 * self.world)
+        self.comm.all_gather(alld, dflag)
+        alld = alld.view(self.world, 2)
+        if float(alld[:, 0].min()) >= 1.0:
+            nl_ = self.nlines
+            plan = dict(mode='deferred', K=dfr['reach'], dfr=dfr, fused=bool(float(alld[:, 1].min()) >= 1.0), dots=False,
+                        keep_r0=False, chunks=[], ulo=E.vec(nl_), uhi=E.vec(nl_), prev_last=E.vec(nl_), next_first=E.vec(nl_))
+            self._a0_key, self._a0 = key, plan
+            self.axis0_mode = 'deferred'
+            return plan
         K = self._window_guess(gam)
         cand = {}
         if not self._force_exact:
@@ -839,7 +911,42 @@ class SlabStepper:
         self._halo_ready = None
 
         # 2. explicit stage, 3. axis-0 sweep
-        if fused:
+        if plan is not None and plan['mode'] == 'deferred':
+            # every line of the slab solved with ZERO boundary values by the single-domain kernels; the first and last plane
+            # of that result go to the neighbours, the 2 x 2 interface systems give the two boundary values of every line, and
+            # the axis-1 sweep adds  ulo * w[i] + uhi * w[n-1-i]  to what it loads (step 4)
+            if fused:
+                if halo_ev is not None and streams:
+                    main.wait_event(halo_ev)
+                E.sweep0_fused(v, Li, Text, 1, 0, fl, self.packs_int[0], self.dx, prm.dt, kappa, prm.theta, self.Tinf, Bi)
+            else:
+                if nl >= 4:                                   # the planes that touch no halo run while the halos travel
+                    ex(2, nl)
+                    if halo_ev is not None and streams:
+                        main.wait_event(halo_ev)
+                    ex(1, 2); ex(nl, nl + 1)
+                else:
+                    if halo_ev is not None and streams:
+                        main.wait_event(halo_ev)
+                    ex(1, nl + 1)
+                mark()
+                E.sweep(0, v, Li, Ai, fl, self.packs_int[0], prm.theta, gam, prm.dt, self.Tinf, Bi)
+            mark()
+            if streams:
+                ev0 = torch.cuda.Event(); ev0.record(main)
+                with torch.cuda.stream(self._comm_stream):
+                    self._comm_stream.wait_event(ev0)
+                    self.comm.exchange_planes(Bi[0], Bi[nl - 1], plan['prev_last'].view(self.ny, self.nz),
+                                              plan['next_first'].view(self.ny, self.nz))
+                    ev1 = torch.cuda.Event(); ev1.record(self._comm_stream)
+                main.wait_event(ev1)
+            else:
+                self.comm.exchange_planes(Bi[0], Bi[nl - 1], plan['prev_last'].view(self.ny, self.nz),
+                                          plan['next_first'].view(self.ny, self.nz))
+            first, last = self.rank == 0, self.rank == self.world - 1
+            E.interface_deferred(Bi[0], Bi[nl - 1], None if first else plan['prev_last'], None if last else plan['next_first'],
+                                 plan['dfr']['omega'], self.nlines, plan['ulo'], plan['uhi'])
+        elif fused:
             # R0 never reaches HBM: both passes of the axis-0 sweep evaluate it from the state (halo planes included,
             # so they must have landed; in an nsub loop they were sent while the previous step's last sweep ran)
             if self.world == 1:
@@ -901,9 +1008,14 @@ class SlabStepper:
             mark()
             ev_x = self._axis0_pipeline(plan, Ai, Bi)
             self._axis0_finish(plan, Ai, Bi, ev_x)
-        mark()
         # 4. local sweeps
-        E.sweep(1, v, Li, Bi, fl, self.packs_int[1], prm.theta, gam, prm.dt, self.Tinf, Ai)
+        if plan is not None and plan['mode'] == 'deferred':
+            E.sweep_corrected(v, Li, Bi, fl, self.packs_int[1], prm.theta, gam, prm.dt, self.Tinf, Ai,
+                              None if self.rank == 0 else plan['ulo'], None if self.rank == self.world - 1 else plan['uhi'],
+                              plan['dfr']['w'])
+        else:
+            mark()
+            E.sweep(1, v, Li, Bi, fl, self.packs_int[1], prm.theta, gam, prm.dt, self.Tinf, Ai)
         mark()
         pk2 = self.packs_int[2]
         sw2 = lambda p0, p1: E.sweep(2, v, E.layout(p1 - p0, self.ny, self.nz, Li.sx), Ai[p0:p1], fl[p0:p1],

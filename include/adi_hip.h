@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 11
+#define ADI_ABI_VERSION 12
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -241,6 +241,37 @@ int adi_interface_solve(const double *d_cond_all, int nranks, int rank, long nli
  * first window of the slab above; NULL where there is no neighbour (boundary value 0, never used). */
 int adi_interface_pair(const double *d_my_lo, const double *d_my_hi, const double *d_prev_hi, const double *d_next_lo,
                        long nlines, double *d_xlo, double *d_xhi, void *stream);
+
+/*
+ * Deferred form of the slab decomposition (ABI v12; no counterpart in the reference, which is single-process).  For slabs
+ * whose sharded-axis lines are all uniform (solid, no Dirichlet cell) the two-pass scheme above is not needed:
+ *   1. every rank runs the ordinary single-domain kernel (adi_explicit_sweep0 / adi_sweep along axis 0, d_xlo = d_xhi =
+ *      NULL) on its slab: each line solved with zero boundary values -> x0.  Planes 0 and nx-1 of x0 are exactly the
+ *      pass-A right-hand sides (gF, gL), so "one ghost plane per sweep" travels to each neighbour and nothing else;
+ *   2. adi_interface_deferred: the 2 x 2 system per boundary and line -> the two interface values of every line;
+ *   3. by linearity  x = x0 + ulo * w[i] + uhi * w[nx-1-i]  with w the decaying homogeneous solution of the uniform
+ *      row (adi_axis0_deferred_setup).  That rank-two update is not applied to x0 in memory: adi_sweep_corrected, the
+ *      axis-1 sweep that consumes the field next (sweep_axis1, adi3d_numba_coeff.py:300), adds it to every value it
+ *      loads -- two planes re-read from L2 instead of a second pass over the slab.
+ * adi_axis0_deferred_setup: w (nx doubles, device) for (theta, gam); entries <= tol are stored as exactly 0 (the kernels
+ *   skip them), *h_reach = number of non-zero entries, *h_omega = w[0].  The form is valid when the weights have decayed
+ *   across the slab (*h_reach < nx): then neither the far end's closure nor the next-but-one slab matters.  Synchronises.
+ * adi_interface_deferred: d_first / d_last = planes 0 / nx-1 of this rank's x0 (dense ny*nz), d_prev_last / d_next_first
+ *   = the neighbours' adjacent planes (NULL: no neighbour) -> d_ulo, d_uhi (dense ny*nz; 0 where there is no neighbour).
+ * adi_sweep_corrected: adi_sweep(axis = 1, ...) reading  in + w[i] * ulo[j][k] + w[nx-1-i] * uhi[j][k]  (d_ulo or d_uhi
+ *   NULL: that term is absent; d_w NULL: plain adi_sweep).
+ */
+int adi_axis0_deferred_setup(int n, double theta, double gam, double tol, double *d_w, double *h_omega, int *h_reach,
+                             void *stream);
+int adi_interface_deferred(const double *d_first, const double *d_last, const double *d_prev_last,
+                           const double *d_next_first, double omega, long nlines, double *d_ulo, double *d_uhi,
+                           void *stream);
+int adi_sweep_corrected(int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
+                        const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux,
+                        int nx, int ny, int nz, long plane_stride, int sparse,
+                        double theta, double gam, double dt, double Tinf,
+                        double *d_out, const double *d_ulo, const double *d_uhi, const double *d_w,
+                        void *d_work, size_t work_bytes, void *stream);
 
 /*
  * adi_step_numba_coeff / adi_step_gpu_coeff: adi3d_numba_coeff.py:290-302, adi3d_gpu_coeff.py:213-230.

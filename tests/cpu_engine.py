@@ -145,6 +145,46 @@ class CpuEngine:
         self.condense(0, variant, CpuLayout(Li.nx, j1 - j0, Li.nz), cut(r0), cut(flags), tuple(cut(t) for t in pack), theta,
                       gam, dt, Tinf, cond)
 
+    # deferred form of the sharded-axis sweep: dense restatements, independent of the product's kernels
+    def lines_all_uniform(self, Li, flags_int, dmask_int):
+        f = flags_int.numpy()
+        if dmask_int is not None and bool(dmask_int.numpy().any()):
+            return False
+        n = f.shape[0]
+        if n < 2:
+            return False
+        ok = ((f[0] & 5) == 5).all() and ((f[-1] & 3) == 3).all() and ((f[1:-1] & 7) == 7).all()
+        both_ends = (((f[0] & 2) == 0) & ((f[-1] & 4) == 0)).any()     # a line with two modified end rows is not uniform
+        return bool(ok and not both_ends)
+
+    def deferred_setup(self, n, theta, gam, tol):
+        tg = theta * gam
+        A = _dense(np.full(n, -tg), np.full(n, 1.0 + 2.0 * tg), np.full(n, -tg))
+        w = tg * np.linalg.solve(A, np.eye(n)[:, 0])
+        reach = int((w > tol).sum())
+        w[w <= tol] = 0.0
+        return dict(w=torch.from_numpy(w), omega=float(w[0]), reach=reach)
+
+    def interface_deferred(self, first, last, prev_last, next_first, omega, nlines, ulo, uhi):
+        lo = ulo.numpy(); hi = uhi.numpy()
+        lo[:] = 0.0; hi[:] = 0.0
+        M = np.array([[1.0, -omega], [-omega, 1.0]])         # unknowns (last of the slab below, first of the slab above)
+        if prev_last is not None:
+            g = np.stack([prev_last.numpy().reshape(-1), first.numpy().reshape(-1)])
+            lo[:] = np.linalg.solve(M, g)[0]
+        if next_first is not None:
+            g = np.stack([last.numpy().reshape(-1), next_first.numpy().reshape(-1)])
+            hi[:] = np.linalg.solve(M, g)[1]
+
+    def sweep_corrected(self, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, ulo, uhi, w_corr):
+        w = w_corr.numpy()
+        x = t_in.numpy().copy()
+        if ulo is not None:
+            x += w[:, None, None] * ulo.numpy().reshape(1, Li.ny, Li.nz)
+        if uhi is not None:
+            x += w[::-1][:, None, None] * uhi.numpy().reshape(1, Li.ny, Li.nz)
+        self.sweep(1, variant, Li, torch.from_numpy(x), flags, pack, theta, gam, dt, Tinf, t_out)
+
     def sweep(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, xlo=None, xhi=None):
         a, b, c, d = _line_systems(axis, t_in, flags, pack, theta, gam, dt, Tinf)
         a = np.moveaxis(a, axis, -1).copy(); b = np.moveaxis(b, axis, -1).copy()

@@ -29,4 +29,4 @@ def test_real_rccl_ranks_match_one_domain():
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     print(r.stdout[-4000:])
     assert r.returncode == 0, r.stdout[-4000:]
-    assert r.stdout.count('rel L-inf vs one domain') == 4
+    assert r.stdout.count('rel L-inf vs one domain') == 5

@@ -43,7 +43,21 @@ def _stiff_case(nx):
     return c
 
 
+def _solid_case(nx, cfl):
+    """all-solid grid, Robin everywhere (per-voxel h), Neumann on both global axis-0 ends: every sharded-axis line is
+    uniform, which is what the deferred form of the sharded-axis sweep needs"""
+    c = _decay_case(nx)
+    rng = np.random.default_rng(13)
+    alpha = c['mat']['k'] / (c['mat']['rho'] * c['mat']['cp'])
+    c.update(mask=np.ones(c['shape'], bool), dt=cfl * c['dx'] ** 2 / alpha, neumann={'x-': 1e5, 'x+': 2e5, 'y-': 5e4},
+             robin_h=rng.uniform(100.0, 600.0, c['shape']), nsteps=3)
+    return c
+
+
 def _case(name):
+    if name.startswith('solid:'):
+        _, nx, cfl = name.split(':')
+        return _solid_case(int(nx), float(cfl))
     if name.startswith('decay:'):
         return _decay_case(int(name.split(':')[1]))
     if name.startswith('stiff:'):
@@ -77,6 +91,7 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q, opts=None):
         st._allow_fused = bool(opts.get('allow_fused', True))
         st._keep_r0 = bool(opts.get('keep_r0', True))
         st._allow_dots = bool(opts.get('allow_dots', True))
+        st._allow_deferred = bool(opts.get('allow_deferred', True))
         T = torch.from_numpy(np.ascontiguousarray(c['T0'][i0:i1]))
         for s in range(nsteps):
             T = st.step(T, prefetch_halo=bool(opts.get('prefetch', False)) and s + 1 < nsteps)
@@ -175,6 +190,30 @@ def test_world_4_and_8_every_interface_form(world, name, sizes, opts, mode):
     from helpers import run_cart_case, rel_linf
     c = _case(name)
     assert sum(sizes) == c['shape'][0] and len(sizes) == world
+    got, modes = _run_world(world, name, sizes, c['nsteps'], opts)
+    assert modes == {mode}, modes
+    want = run_cart_case(orc, c)['T_final']
+    assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
+
+
+@pytest.mark.parametrize('world,name,sizes,opts,mode', [
+    (2, 'solid:128:0.1', [64, 64], dict(prefetch=True), 'deferred'),
+    (3, 'solid:96:0.1', [32, 32, 32], dict(prefetch=True, allow_fused=False), 'deferred'),
+    (4, 'solid:126:0.1', [32, 30, 32, 32], dict(prefetch=True), 'deferred'),                   # uneven slabs
+    (4, 'solid:256:2.0', [64] * 4, dict(prefetch=True), 'deferred'),                           # weights reach ~60 rows
+    (8, 'solid:192:0.1', [24] * 8, dict(prefetch=True), 'deferred'),
+    (4, 'solid:128:0.1', [32] * 4, dict(prefetch=True, allow_deferred=False), 'slab'),         # the two-pass form on the same case
+    (4, 'solid:64:200', [16] * 4, dict(prefetch=True), 'exact'),                               # nothing decays: not eligible
+    (3, 'decay:96', [32, 32, 32], dict(prefetch=True), 'slab'),                                # voids: lines not uniform
+])
+def test_deferred_form_matches_single_domain(world, name, sizes, opts, mode):
+    """all-solid slabs whose homogeneous solution decays across a slab: the sharded-axis sweep is the single-domain
+    solve with zero boundary values + one plane to each neighbour + a rank-two correction added by the axis-1 sweep;
+    chosen collectively, never when a line is not uniform or the weights have not decayed"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import adi_oracle as orc
+    from helpers import run_cart_case, rel_linf
+    c = _case(name)
     got, modes = _run_world(world, name, sizes, c['nsteps'], opts)
     assert modes == {mode}, modes
     want = run_cart_case(orc, c)['T_final']

@@ -38,6 +38,7 @@ def _run_slabs(c, world, sizes, nsteps, opts=None, modes=None):
             st._allow_fused = bool(o.get('allow_fused', True))
             st._allow_dots = bool(o.get('allow_dots', True))
             st._keep_r0 = bool(o.get('keep_r0', True))
+            st._allow_deferred = bool(o.get('allow_deferred', True))
             if 'dots_max' in o:
                 st.DOTS_MAX_NONUNIFORM = o['dots_max']
             T = hip.to_device(np.ascontiguousarray(c['T0'][i0:i1]))
@@ -128,7 +129,62 @@ def test_slabs_interface_forms_agree(cfl, opts, mode):
     assert rel_linf(got, want) <= 1e-13, rel_linf(got, want)
 
 
-def test_slabs_window_solid_512_lines():
+@pytest.mark.parametrize('shape,sizes,cfl,opts,mode', [
+    ((256, 16, 64), [64] * 4, 3.0, dict(prefetch=True), 'deferred'),                       # weights reach ~50 of 64 rows
+    ((256, 16, 64), [64] * 4, 3.0, dict(prefetch=True, allow_fused=False), 'deferred'),    # explicit stage as its own kernel
+    ((254, 16, 64), [64, 62, 64, 64], 3.0, dict(prefetch=True), 'deferred'),               # uneven slabs
+    ((1024, 16, 32), [512, 512], 200.0, dict(prefetch=True), 'deferred'),                  # the bench's slab thickness and cfl
+    ((1536, 16, 32), [512] * 3, 200.0, dict(prefetch=True), 'deferred'),                   # a middle rank: both corrections
+    ((192, 24, 40), [64] * 3, 1.0, dict(prefetch=True), 'deferred'),                       # nz not a multiple of 16: GENERAL kernels
+    ((128, 70, 16), [64, 64], 1.0, dict(prefetch=True), 'deferred'),                       # ragged axis-1 lines
+    ((256, 16, 64), [64] * 4, 3.0, dict(prefetch=True, allow_deferred=False), 'slab'),     # the two-pass form on the same grid
+    ((256, 16, 64), [64] * 4, 300.0, dict(prefetch=True), 'exact'),                        # nothing decays across 64 rows
+])
+def test_slabs_deferred_form(shape, sizes, cfl, opts, mode):
+    """all-solid slabs: the sharded-axis sweep as the single-domain (fused) kernel with zero boundary values + one plane to
+    each neighbour + 2 x 2 interface systems + the rank-two correction added by the axis-1 sweep's loads (FAST and GENERAL
+    strided kernels), against the single-domain HIP step: <= 1e-13"""
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    rng = np.random.default_rng(31)
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=np.ones(shape, bool),
+             T0=rng.uniform(20.0, 1200.0, shape), dir_mask=None, dir_value=None, neumann={'x-': 3e5, 'x+': 1e5, 'y+': 2e5},
+             robin_h=rng.uniform(100.0, 600.0, shape), Tinf=20.0, theta=0.5, dt=cfl * dx * dx / alpha, nsteps=3,
+             births=None)
+    modes = set()
+    got = _run_slabs(c, len(sizes), sizes, 3, opts, modes)
+    assert modes == {mode}, modes
+    want = run_cart_case(hip, c)['T_final']
+    assert rel_linf(got, want) <= 1e-13, rel_linf(got, want)
+
+
+def test_slabs_deferred_form_declines_non_uniform_lines():
+    """one void cell, one Dirichlet cell: a sharded-axis line is no longer uniform, so no rank may take the deferred form"""
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    rng = np.random.default_rng(32)
+    shape = (256, 16, 64)
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    for kind in ('void', 'dirichlet'):
+        mask = np.ones(shape, bool)
+        dm = None
+        if kind == 'void':
+            mask[200, 3, 5] = False                          # on the last rank only
+        else:
+            dm = np.zeros(shape, bool); dm[10, 2, 7] = True  # on the first rank only
+        c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask, T0=rng.uniform(20.0, 1200.0, shape),
+                 dir_mask=dm, dir_value=(None if dm is None else 50.0), neumann=None, robin_h=300.0, Tinf=20.0, theta=0.5,
+                 dt=3.0 * dx * dx / alpha, nsteps=2, births=None)
+        modes = set()
+        got = _run_slabs(c, 4, [64] * 4, 2, dict(prefetch=True), modes)
+        assert modes == {'slab'}, (kind, modes)
+        want = run_cart_case(hip, c)['T_final']
+        assert rel_linf(got, want) <= 1e-13, (kind, rel_linf(got, want))
+
+
+@pytest.mark.parametrize('deferred,mode', [(False, 'window'), (True, 'deferred')])
+def test_slabs_window_solid_512_lines(deferred, mode):
     """all-solid grid (the FAST uniform-interior kernels) on 2 slabs of 256 planes, 32-plane windows"""
     import adi_thermal_fields_amd.adi3d_hip_coeff as hip
     rng = np.random.default_rng(8)
@@ -139,8 +195,8 @@ def test_slabs_window_solid_512_lines():
              T0=rng.uniform(20.0, 1200.0, shape), dir_mask=None, dir_value=None, neumann=None,
              robin_h=500.0, Tinf=20.0, theta=0.5, dt=1.0 * dx * dx / alpha, nsteps=2, births=None)
     modes = set()
-    got = _run_slabs(c, 2, [256, 256], 2, dict(prefetch=True), modes)
-    assert modes == {'window'}, modes
+    got = _run_slabs(c, 2, [256, 256], 2, dict(prefetch=True, allow_deferred=deferred), modes)
+    assert modes == {mode}, modes
     want = run_cart_case(hip, c)['T_final']
     assert rel_linf(got, want) <= 1e-13, rel_linf(got, want)
 
@@ -210,18 +266,21 @@ def test_slab_step_over_real_rccl_self_loop():
         dx = 1e-3
         alpha = 54.0 / (7800.0 * 490.0)
         T0 = rng.uniform(20.0, 900.0, shape)
-        for cfl, opts in ((150.0, {}), (150.0, dict(allow_dots=False)), (0.05, {}), (300.0, dict(force_exact=True))):
+        solid = np.ones(shape, bool)
+        for cfl, opts in ((150.0, {}), (150.0, dict(allow_dots=False)), (0.05, {}), (300.0, dict(force_exact=True)),
+                          (3.0, dict(solid=True)), (3.0, dict(solid=True, allow_fused=False))):
             outs = []
             for comm in (dist_slab.LoopbackComm(4, 1), dist_slab.SelfLoopDistComm(4, 1)):
-                st = dist_slab.SlabStepper(mask, dx, hip.Material(7800.0, 490.0, 54.0), hip.Params(cfl * dx * dx / alpha, 0.5),
-                                           20.0, robin_h=300.0, comm=comm)
+                st = dist_slab.SlabStepper(solid if opts.get('solid') else mask, dx, hip.Material(7800.0, 490.0, 54.0),
+                                           hip.Params(cfl * dx * dx / alpha, 0.5), 20.0, robin_h=300.0, comm=comm)
+                st._allow_fused = opts.get('allow_fused', True)
                 st._allow_dots = opts.get('allow_dots', True); st._force_exact = opts.get('force_exact', False)
                 T = hip.to_device(T0)
                 for s in range(4):
                     T = st.step(T, prefetch_halo=(s < 3))
                 torch.cuda.synchronize()
                 outs.append((T.get(), st.axis0_mode))
-            assert outs[0][1] == outs[1][1]
+            assert outs[0][1] == outs[1][1] and (outs[0][1] == 'deferred') == bool(opts.get('solid'))
             assert np.array_equal(outs[0][0], outs[1][0]), (cfl, opts, outs[0][1])
     finally:
         dist.destroy_process_group()
