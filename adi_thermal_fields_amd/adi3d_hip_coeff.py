@@ -506,6 +506,14 @@ def _as_state(Tn, grid):
     kind = 'field' if isinstance(Tn, DeviceField) else ('torch' if isinstance(Tn, torch.Tensor) else 'numpy')
     if kind == 'numpy':
         Tn = np.asarray(Tn)
+        # Called exactly like the reference (host arrays in, host array out) the step also READS grid.mask like the
+        # reference does (adi3d_numba_coeff.py:294-301 pass grid.mask to every stage): the host mask is re-uploaded and
+        # compared with the device copy, so a mask mutated in place since the last assignment / pack build is seen
+        # (1 B/cell next to the 16 B/cell this path moves anyway; an unchanged mask keeps flags, version and packs).
+        # Device-resident stepping (DeviceField / tensor state) is the opt-in fast path: there `grid.mask = ...`,
+        # grid.sync_mask() or a pack rebuild is the synchronisation point.
+        if getattr(grid, '_mask', None) is not None and hasattr(grid, 'sync_mask'):
+            grid.sync_mask()
     assert tuple(Tn.shape) == grid.shape
     return grid.layout.to_layout(Tn, torch.float64), kind
 

@@ -19,6 +19,16 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
     const int tid = threadIdx.x;
     long tile = xcd_chunk_tile(blockIdx.x, ntiles);
     if (FUSE && fz.kg > 0) tile = tile_jfast(tile, fz);
+    if constexpr (!FUSE) {
+        // deferred interface correction (SweepScal::c_*): every plane of the slab re-reads the same two correction planes.
+        // Give each XCD a fixed eighth of the k-tiles over ALL planes instead of a chunk of whole planes: its share of the
+        // two planes (2 x ny x nz/8 values: 512 KiB at 512^2) then stays in its L2 for the whole launch.
+        if (s.c_w != nullptr && (tiles_inner & 7) == 0) {
+            const unsigned kx = (unsigned)tiles_inner >> 3, x = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+            const unsigned pl = idx / kx;
+            tile = (long)pl * tiles_inner + (long)(x * kx + (idx - pl * kx));
+        }
+    }
     const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
     const int ti = (int)(tile - to * tiles_inner);
     const int kk = tid & (LINES - 1), sg = tid >> (__ffs(LINES) - 1);   // LINES is a power of two

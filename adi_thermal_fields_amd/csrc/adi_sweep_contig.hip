@@ -133,7 +133,8 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
     // line: 155 Gcell/s at 256^3 against 311 at nz = 512)
     // Segment counts that are not a power of two leave lanes of the in-wave PCR idle (n = 320: 20 segments of 16 rows in 32
     // lanes, 37 % of every wave padding; 209 against 270 Gcell/s at nz = 256).  Where 20, 24 or 28 rows per lane cut the
-    // line into exactly 16, 32 or 64 segments the FAST kernel takes that many (n = 320, 384, 448, 640, 768, 896, 1280, ...)
+    // line into exactly 16 or 32 segments the FAST kernel takes that many (n = 320, 384, 448, 640, 768, 896; lines beyond
+    // kMaxFastLine = 1024 rows never get here: sweep_entry sends them to the thread-per-line kernel)
     int Mf = M;
     const auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     int exact = 0;

@@ -1,6 +1,7 @@
 // adi_sweep_contig_x.hip -- the FAST kernel of the contiguous-axis sweep (adi_contig_dev.hpp) with 20, 24 and 28 rows per lane:
-// lines of 320 / 384 / 448 rows (16 segments), 640 / 768 / 896 (32), 1280 / 1536 / 1792 (64).  With 16 rows per lane such
-// lines need 20 - 28 of 32 (40 - 56 of 64) lanes of the in-wave interface solve and the rest of every wave is padding: 222 - 241
+// lines of 320 / 384 / 448 rows (16 segments) and 640 / 768 / 896 (32); 64 segments would be 1280 / 1536 / 1792 rows, beyond the
+// kMaxFastLine = 1024 rows the in-register kernels are given, so that branch is never taken.  With 16 rows per lane such
+// lines need 20 - 28 of 32 lanes of the in-wave interface solve and the rest of every wave is padding: 222 - 241
 // Gcell/s against 324 - 333 with the exact fit (345 at 512 rows).  A translation unit of its own so that the build stays
 // parallel (12 more instantiations of a 100 - 145 VGPR kernel).
 #include "adi_contig_dev.hpp"

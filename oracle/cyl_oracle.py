@@ -20,8 +20,9 @@ import numpy as np
 class GridCyl:  # adi3d_cyl_phi_v3.py:33-43
     def __init__(self, nr, nphi, nz, dr, dphi, dz, R, R_in=0.0):
         # R_in: the annular grid quick_spiral_deposition_gif_v5.py:80 asks for (the reference's constructor raises TypeError,
-        # SURVEY D1): r shifted by the inner radius, everything else as written.  PARITY UNPINNED for R_in != 0 -- the
-        # reference cannot run it; R_in = 0 is pinned by the golden vectors.
+        # SURVEY D1): r shifted by the inner radius, everything else as written.  R_in != 0 is pinned by
+        # tests/golden/cyl_spiral_annulus.npz (the reference's own numeric loop run with a GridCyl subclass that supplies the
+        # missing constructor, tests/golden/make_golden_spiral.py); R_in = 0 by the other cylindrical golden vectors.
         self.nr = int(nr); self.nphi = int(nphi); self.nz = int(nz)
         self.dr = float(dr); self.dphi = float(dphi); self.dz = float(dz)
         self.R = float(R)

@@ -151,6 +151,30 @@ def test_packs_of_one_grid_on_another_grid_follow_the_reference(hip):
     assert rel_linf(outs[0], outs[1]) <= TOL, rel_linf(outs[0], outs[1])
 
 
+def test_in_place_mask_change_is_seen_by_the_numpy_step(hip):
+    """The reference reads grid.mask at every step (adi3d_numba_coeff.py:294-301): a mask mutated IN PLACE, with no
+    `grid.mask = ...` and no pack rebuild, changes the next step.  Called like the reference (NumPy in, NumPy out) the HIP
+    step re-uploads and compares the host mask, so it follows; the stale packs are read densely, as the reference does."""
+    from oracle import adi_oracle as orc
+    c = cases.cart_case('long_line_70')
+    rng = np.random.default_rng(9)
+    flip = rng.random(c['shape']) > 0.97
+    outs = []
+    for api in (hip, orc):
+        grid = api.Grid3D(*c['shape'], c['dx'], c['mask'])
+        mat = api.Material(**c['mat'])
+        prm = api.Params(c['dt'], c['theta'])
+        packs = api.precompute_coeff_packs_unified(grid, mat, neumann=c['neumann'], robin_h=c['robin_h'])
+        step = getattr(api, 'adi_step_hip_coeff', None) or api.adi_step_numba_coeff
+        T = np.array(c['T0'], dtype=np.float64)
+        T = step(T, grid, mat, prm, packs, Tinf=c['Tinf'])
+        grid.mask[flip] = ~grid.mask[flip]                    # in place: no assignment, no rebuild
+        for _ in range(2):
+            T = step(T, grid, mat, prm, packs, Tinf=c['Tinf'])
+        outs.append(T)
+    assert rel_linf(outs[0], outs[1]) <= TOL, rel_linf(outs[0], outs[1])
+
+
 def test_second_pack_set_on_an_unchanged_grid_keeps_the_first_fresh(hip):
     """precompute_coeff_packs_unified re-uploads the mask every time (the documented synchronisation point); when the
     mask has not changed the flags and the mask version stand, so packs built earlier (a Dirichlet-vs-Robin comparison,
@@ -713,7 +737,8 @@ def test_no_fallback_promise_is_learnt_per_configuration(hip):
 def test_exact_fit_row_counts(hip, n, ax):
     """lines whose length is 20, 24 or 28 times a power of two: the FAST kernels take 20 / 24 / 28 rows per lane (thread) so
     that the line fills the lanes of the interface solve exactly (adi_sweep_contig_x.hip, adi_sweep_strided_x.hip).  Solid
-    blocks, voids, a curved solid and the general pack, against the oracle."""
+    blocks, voids, a curved solid and the general pack, against the oracle.  n = 1280 is NOT an exact-fit case: lines
+    beyond 1024 rows take the thread-per-line kernel (k_sweep_generic) on every axis; it is here as that path's test."""
     from oracle import adi_oracle as orc
     alpha = 54.0 / (7800.0 * 490.0)
     for kind in ('solid', 'holes', 'ellipsoid', 'general'):

@@ -275,10 +275,11 @@ def test_config5_shrink_64x64x80_oracle_hip_and_4_slabs():
 def test_config5_full_256x256x320_4_slabs_match_one_domain():
     """the full 256 x 256 x 320 synthetic head (21 M cells, 6 M in the mask), layers of 2 planes (160 births, pack
     rebuild per birth), cfl 2000: 4 slabs of 64 planes in one process on one GPU against the one-domain HIP run of the
-    same loop.  theta = 1 here: with the driver's default theta = 0.5 the reference's factored scheme is unstable on this
-    mask at this size (its 1-D operators do not commute on an irregular mask) -- the CPU oracle and the HIP path blow up
-    together, to 1e21 after 43 steps, still agreeing to 4e-12 relative (scripts/_tmp run, not a test: nothing to assert
-    on a diverged field) -- while theta = 1 makes every sweep a max-norm contraction."""
+    same loop.  theta = 1 here: with the driver's default theta = 0.5 the reference's scheme leaves the physical range on
+    this mask at this size (reference defect D9; scripts/d9_probe.py -> profiles/r03_d9_probe.txt, CPU
+    oracle alone: inside [20, 1000] through step 22, -1.3e5 / +1.2e4 at step 23, +-7.2e7 at step 26, +-8e16 at step 43,
+    growing 2 - 10x per step) -- nothing to assert on a diverged field -- while theta = 1 makes every sweep a max-norm
+    contraction."""
     import adi_thermal_fields_amd.adi3d_hip_coeff as hip
     from adi_thermal_fields_amd import waam
     shape = (256, 256, 320)
@@ -299,10 +300,10 @@ def test_config5_full_256x256x320_4_slabs_match_one_domain():
 def test_config5_full_size_theta_half_as_specified_before_divergence():
     """BASELINE.json configs[4] exactly as SURVEY.md 8(d) writes it -- 256 x 256 x 320 synthetic head, layers of 2 planes,
     cfl 2000, theta = 0.5, Robin h = 40, Ts = 1000 -- over the window in which the reference scheme is still bounded.
-    At theta = 0.5 / cfl = 2000 the factored scheme itself is unstable on this mask (reference defect D9, DESIGN.md
-    section 6: in the pinned oracle the field stays inside [20, 1000] through step 20, reaches +-1.3e5 at step 23 and
-    +-7.2e7 at step 26), so the full-size comparison with the CPU oracle covers the first 21 births = 20 steps:
-    HIP == OpenMP oracle to 1e-10."""
+    At theta = 0.5 / cfl = 2000 the scheme leaves the physical range on this mask (reference defect D9, DESIGN.md
+    section 6; scripts/d9_probe.py -> profiles/r03_d9_probe.txt: the pinned oracle stays inside [20, 1000] through step
+    22, reaches -1.3e5 / +1.2e4 at step 23 and +-7.2e7 at step 26), so the full-size comparison with the CPU oracle
+    covers the first 21 births = 20 steps: HIP == OpenMP oracle to 1e-10."""
     from oracle import adi_oracle as orc
     import adi_thermal_fields_amd.adi3d_hip_coeff as hip
     from adi_thermal_fields_amd import waam
