@@ -24,6 +24,9 @@ constexpr bool kBufStrided = ADI_BUF_STRIDED != 0;
 #ifndef ADI_FUSE_D
 #define ADI_FUSE_D 10    // rows of j-neighbour loads in flight per thread in the fused FAST kernels (512^3: 2 0.77 ms, 4 0.70, 8 0.68; with the results pinned in the loader 8 0.64-0.66, 10 0.63-0.65, 12 0.67, 16 0.90: spills)
 #endif
+#ifndef ADI_FUSE_D_MIXED
+#define ADI_FUSE_D_MIXED 6   // the build that carries the surface-segment lanes (MIXED = true) has 12 fewer registers to give: with 10 rows in flight it spills (20 B/lane + 102 SGPRs) and runs 0.73 ms on the all-solid 512^3 box and 0.79 ms on the ellipsoid; 8: 0.67 / 0.72, 6: 0.665 / 0.71 (the build without them: 0.65)
+#endif
 #ifndef ADI_FUSE_OCC
 #define ADI_FUSE_OCC 4   // waves per SIMD the fused FAST kernels are compiled for (4: two 512-thread workgroups per CU; 3 measures the same, 2 with deeper prefetch is slower)
 #endif

@@ -51,8 +51,12 @@ inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok,
     P.Mg = strided_rows_per_thread(n);
     P.Lpg = next_pow2((n + P.Mg - 1) / P.Mg);
     P.Mf = 0; P.Lpf = 0; P.lines_f = 0; P.tiles_inner_f = 0; P.ntiles_f = 0; P.ratio = 1; P.lds_f = 0;
+#ifndef ADI_DENSE_LINES
+#define ADI_DENSE_LINES 8
+#endif
     int lines = 8;                                    // lines per tile of the GENERAL kernel (8 B * lines contiguous per row)
     if (P.Mg > 8 && lines * P.Lpg > 512) lines = 8;
+    if (!want_fast && P.Mg == 8 && ADI_DENSE_LINES * P.Lpg <= 1024) lines = ADI_DENSE_LINES;   // the dense (42 B/cell) sweeps
     const int maxg = (P.Mg <= 8) ? 1024 : 512;
     if (want_fast && n >= 64 && (long)n * g.stride < (1L << 31)) {   // 32-bit element offsets in the FAST kernels
         int mf = 0, lf = 0;
