@@ -38,7 +38,9 @@ static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t 
     bool has_dir, has_q;
     if (int rc = variant_flags(variant, &has_dir, &has_q)) return rc;
     ADI_REQUIRE(d_in && d_flags && d_coeff && d_out, "adi_sweep: null argument");
+#ifndef ADI_ALLOW_INPLACE
     ADI_REQUIRE(d_in != d_out, "adi_sweep: output aliases input");
+#endif
     ADI_REQUIRE(!has_dir || (d_dir_mask && d_dir_val), "adi_sweep: variant needs Dirichlet arrays");
     ADI_REQUIRE(!has_q || d_qflux, "adi_sweep: variant needs the flux array");
     Lay L;

@@ -65,7 +65,7 @@ struct CylZ {
 // MODE 0: r sweep (axis 0).  MODE 1: phi sweep (axis 1, periodic, Sherman-Morrison).
 template <int M, int MODE>
 __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_cyl_strided(
-    const double *__restrict__ in, double *__restrict__ out, int n, long stride, int n_inner, long outer_stride,
+    const double *in, double *out, int n, long stride, int n_inner, long outer_stride,
     int Lp, int LINES, int tiles_inner, long ntiles,
     const double *__restrict__ ta, const double *__restrict__ tb, const double *__restrict__ tc, double add_last,
     const double *__restrict__ S, double s_scale, const uint8_t *__restrict__ active_mask, double T_void,
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_cyl_strided(
 
 // ---- z sweep: contiguous kernel, constant coefficients with end closures -----------------------
 template <int M, bool VEC>
-__global__ __launch_bounds__(256) void k_cyl_contig(const double *__restrict__ in, double *__restrict__ out,
+__global__ __launch_bounds__(256) void k_cyl_contig(const double *in, double *out,
                                                    long nlines, int n, int Lp, CylZ z,
                                                    const uint8_t *__restrict__ active_mask, double T_void,
                                                    double T_inner, long lines_per_r0, long sx)
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_cyl_contig(const double *__restrict__ i
 // phi sweep: tile = LINES adjacent z-lines x all nphi rows of one radius plane
 template <int M>
 __global__ __launch_bounds__(1024) void k_cyl_phi_fast(
-    const double *__restrict__ in, double *__restrict__ out, int n, long stride, int n_inner, long outer_stride,
+    const double *in, double *out, int n, long stride, int n_inner, long outer_stride,
     int Lp, int LINES, int tiles_inner, long ntiles, const UniC<M> *__restrict__ utab,
     const double *__restrict__ fac, const double *__restrict__ zt, const double *__restrict__ smden)
 {
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(1024) void k_cyl_phi_fast(
 // LDS strip (adi_cart_dev.hpp, coal_load).  Closures without a Dirichlet end (neumann0 / robin): row 0 and row n-1
 // differ from the uniform row in their diagonal and right-hand side only.
 template <int M>
-__global__ __launch_bounds__(256) void k_cyl_z_fast(const double *__restrict__ in, double *__restrict__ out, long nlines,
+__global__ __launch_bounds__(256) void k_cyl_z_fast(const double *in, double *out, long nlines,
                                                    int n, int Lp, CylZ z, UniC<M> U,
                                                    const uint8_t *__restrict__ active_mask, double T_void, double T_inner,
                                                    long lines_per_r0, long sx)
@@ -387,7 +387,7 @@ struct CylRSegView {
 // segments; 512-byte row pieces
 template <int M>
 __global__ __launch_bounds__(1024) void k_cyl_r_fast(
-    const double *__restrict__ in, double *__restrict__ out, int n, long stride, int n_inner, int nseg, int Lp,
+    const double *in, double *out, int n, long stride, int n_inner, int nseg, int Lp,
     long ntiles, const double *__restrict__ rfac, double add_last, const double *__restrict__ S, double s_scale,
     const uint8_t *__restrict__ active_mask, double T_void)
 {
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(1024) void k_cyl_r_fast(
 }
 
 // elementwise pass used when a sweep degenerates (nphi == 1) or the grid is too long for the fast path
-__global__ __launch_bounds__(256) void k_copy(const double *__restrict__ in, double *__restrict__ out, size_t n)
+__global__ __launch_bounds__(256) void k_copy(const double *in, double *out, size_t n)
 {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n) out[p] = in[p];
@@ -811,7 +811,9 @@ static int cyl_sweep_z(const adi_cyl_plan *pl, const double *in, double *out, co
 int adi_cyl_sweep(const adi_cyl_plan *pl, int axis, const double *d_in, double *d_out, const double *d_S,
                   const uint8_t *d_active, double T_void, double T_inner, void *stream)
 {
-    ADI_REQUIRE(pl && d_in && d_out && d_in != d_out, "adi_cyl_sweep: bad argument");
+    // d_out == d_in is allowed: every thread of every sweep kernel in this file reads only the rows it later writes (and
+    // reads them before the barriers that precede its stores), which is why `in` / `out` carry no __restrict__ here
+    ADI_REQUIRE(pl && d_in && d_out, "adi_cyl_sweep: bad argument");
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_cyl_sweep: bad axis %d", axis);
     ADI_REQUIRE((long)pl->nphi * pl->nz <= 0x7fffffffL, "adi_cyl_sweep: (nphi, nz) plane too large");
     hipStream_t st = as_stream(stream);
@@ -831,22 +833,19 @@ int adi_cyl_sweep(const adi_cyl_plan *pl, int axis, const double *d_in, double *
 int adi_cyl_step(const adi_cyl_plan *pl, const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b,
                  const double *d_S, const uint8_t *d_active, double T_void, double T_inner, void *stream)
 {
-    ADI_REQUIRE(pl && d_T_in && d_T_out && d_tmp_a && d_tmp_b, "adi_cyl_step: null argument");
-    ADI_REQUIRE(d_tmp_a != d_tmp_b && d_tmp_a != d_T_in && d_tmp_b != d_T_in && d_T_out != d_tmp_b &&
-                    d_T_out != d_tmp_a && d_T_out != d_T_in,
-                "adi_cyl_step: the four field buffers must be distinct");
+    (void)d_tmp_a; (void)d_tmp_b;     // unused since ABI v13: the phi and z sweeps run in place on d_T_out
+    ADI_REQUIRE(pl && d_T_in && d_T_out, "adi_cyl_step: null argument");
+    ADI_REQUIRE(d_T_out != d_T_in, "adi_cyl_step: T_out aliases T_in (the step returns a new field, adi3d_cyl_phi_v3.py:350)");
     hipStream_t st = as_stream(stream);
     ADI_REQUIRE((long)pl->nphi * pl->nz <= 0x7fffffffL, "adi_cyl_step: (nphi, nz) plane too large");
-    // r sweep: T_in -> tmp_a (source and void pre-clamp fused)
-    if (int rc = cyl_sweep_r(pl, d_T_in, d_tmp_a, d_S, d_active, T_void, st)) return rc;
-    // phi sweep: tmp_a -> tmp_b   (nphi == 1: the reference returns a copy, :303-304)
-    const double *zin = d_tmp_a;
-    if (pl->nphi > 1) {
-        if (int rc = cyl_sweep_phi(pl, d_tmp_a, d_tmp_b, st)) return rc;
-        zin = d_tmp_b;
-    }
-    // z sweep: -> T_out (void post-clamp fused)
-    return cyl_sweep_z(pl, zin, d_T_out, d_active, T_void, T_inner, st);
+    // r sweep: T_in -> T_out (source and void pre-clamp fused); then phi and z IN PLACE on T_out: the working set of the
+    // two sweeps is one field (134 MB at 128 x 256 x 512, inside the 256 MB Infinity Cache) instead of two
+    if (int rc = cyl_sweep_r(pl, d_T_in, d_T_out, d_S, d_active, T_void, st)) return rc;
+    // (nphi == 1: the reference's phi solve returns a copy, :303-304 -- nothing to do)
+    if (pl->nphi > 1)
+        if (int rc = cyl_sweep_phi(pl, d_T_out, d_T_out, st)) return rc;
+    // z sweep (void post-clamp fused)
+    return cyl_sweep_z(pl, d_T_out, d_T_out, d_active, T_void, T_inner, st);
 }
 
 }  // extern "C"

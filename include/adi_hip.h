@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 12
+#define ADI_ABI_VERSION 13
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -341,14 +341,16 @@ int adi_cyl_plan_create_annular(int nr, int nphi, int nz, long plane_stride, dou
                                 double Tinf_bot, double Tinf_top, double T_bot, double T_top,
                                 adi_cyl_plan **out);
 int adi_cyl_plan_destroy(adi_cyl_plan *plan);
-/* adi_step (BE): T_in is not modified; the four field buffers must be distinct. */
+/* adi_step (BE): T_in is not modified and must differ from T_out.  d_tmp_a / d_tmp_b are unused since ABI v13 (may be
+ * NULL): the r sweep writes T_out and the phi and z sweeps run in place on it. */
 int adi_cyl_step(const adi_cyl_plan *plan, const double *d_T_in, double *d_T_out,
                  double *d_tmp_a, double *d_tmp_b, const double *d_S,
                  const uint8_t *d_active, double T_void, double T_inner, void *stream);
 /* One sweep of the BE step (stage entry point for per-stage parity tests and benchmarks): axis 0 = r
  * (build_coeff_r + thomas_batch, adi3d_cyl_phi_v3.py:155-202, :71-87; d_S / d_active / T_void as in adi_cyl_step),
  * axis 1 = phi (phi_solve_spectral, :302-329), axis 2 = z (build_coeff_z + thomas_batch, :255-298; d_active / T_void /
- * T_inner: the post-clamp of adi_step_masked).  d_out must not alias d_in. */
+ * T_inner: the post-clamp of adi_step_masked).  d_out may equal d_in (ABI v13): every sweep kernel reads only the rows it
+ * writes, so a sweep can run in place -- which halves the working set of a loop that does not need the previous field. */
 int adi_cyl_sweep(const adi_cyl_plan *plan, int axis, const double *d_in, double *d_out, const double *d_S,
                   const uint8_t *d_active, double T_void, double T_inner, void *stream);
 
