@@ -55,18 +55,19 @@ SIGNATURES = {
                                         c_double, c_void_p, c_int, c_int, c_void_p]),
     'adi_sweep': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double,
-                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                          c_void_p, c_void_p, c_void_p, c_double_p, c_void_p, c_size_t, c_void_p]),
+    'adi_face_constants': (c_int, [c_double, c_double, c_double, c_int_p, c_double_p, c_int_p, c_double_p, c_double_p, c_int_p]),
     'adi_sweep_workspace_bytes': (c_int, [c_int, c_int, c_int, c_int, c_long, ctypes.POINTER(c_size_t)]),
     'adi_sweep_condense': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double,
-                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+                                   c_void_p, c_double_p, c_void_p, c_size_t, c_void_p]),
     'adi_explicit_fused_supported': (c_int, [c_int, c_int, c_int, c_long, c_int]),
     'adi_explicit_sweep0': (c_int, [c_int, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double, c_double,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p, c_double_p, c_void_p, c_size_t, c_void_p]),
     'adi_explicit_condense0': (c_int, [c_int, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double,
-                                       c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                       c_double, c_void_p, c_void_p, c_double_p, c_void_p, c_size_t, c_void_p]),
     'adi_axis0_dots_supported': (c_int, [c_int, c_int, c_int, c_long]),
     'adi_axis0_dots_workspace': (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     'adi_axis0_dots_setup': (c_int, [c_int, c_double, c_double, c_void_p, c_void_p]),
@@ -83,13 +84,13 @@ SIGNATURES = {
     'adi_interface_deferred': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_long, c_void_p, c_void_p, c_void_p]),
     'adi_sweep_corrected': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_double_p, c_void_p, c_size_t, c_void_p]),
     'adi_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_pp, c_void_p, c_void_p,
                          c_void_pp, c_int, c_int, c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double,
-                         c_double, c_double, c_double, c_void_p, c_size_t, c_void_p]),
+                         c_double, c_double, c_double, c_double_p, c_void_p, c_size_t, c_void_p]),
     'adi_step_queued': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_pp, c_void_p, c_void_p,
                          c_void_pp, c_int, c_int, c_int, c_int, c_int, c_long, c_double, c_double, c_double, c_double,
-                         c_double, c_double, c_double, c_void_p, c_size_t, c_void_p, c_void_p]),
+                         c_double, c_double, c_double, c_double_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     'adi_morph6': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'adi_flood_outside': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int_p, c_void_p]),
     'adi_pack_frame_f32be': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p]),

@@ -359,6 +359,7 @@ class AxisCoeffPack:
         # Set by precompute_coeff_packs_unified only: coeff/qflux are non-zero just on cells exposed along the
         # pack's axis, so the sweep may skip loading them elsewhere.  Hand-built packs are read densely.
         self.sparse_ok = False
+        self.face_consts = None        # (c-, c+, q-, q+) when built from per-face scalars (precompute_coeff_packs_unified)
         self._fractions = None         # (grid, axis, mask version) the byte accounting is evaluated from, on demand
         self._exposed_fraction = 1.0   # fraction of cells exposed along the axis
         self._dir_fraction = 1.0
@@ -402,6 +403,8 @@ class AxisCoeffPack:
         """HBM bytes per cell the sweep of this pack must move (its inputs + the output): the byte count of
         the roofline (SURVEY.md 8(d) variant rule)."""
         fe = self.exposed_fraction if self.sparse_ok else 1.0
+        if self.sparse_ok and self.face_consts is not None:
+            fe = 0.0                                      # per-face scalars: coeff / qflux are not read at all
         b = 8.0 + 1.0 + 8.0 + 8.0 * fe                    # in, flags, out, coeff
         if self.has_q:
             b += 8.0 * fe
@@ -438,6 +441,22 @@ def _face_spec(spec, L, keep):
     t = L.to_layout(spec, torch.float64)
     keep.append(t)
     return (_lib.FACE_FIELD, 0.0, t)
+
+
+def _face_constants(grid, mat, h_modes, h_scalars, q_modes, q_scalars):
+    """per axis (c-, c+, q-, q+) as a ctypes array of 4 doubles, or None where a face of the axis carries a per-voxel field:
+    what the sweeps take as `h_face_consts` instead of loading coeff / qflux at the exposed cells (adi_face_constants)"""
+    consts = (ctypes.c_double * 12)()
+    valid = (ctypes.c_int * 3)()
+    check(lib.adi_face_constants(grid.dx, mat.rho, mat.cp, (ctypes.c_int * 6)(*h_modes), (ctypes.c_double * 6)(*h_scalars),
+                                 (ctypes.c_int * 6)(*q_modes), (ctypes.c_double * 6)(*q_scalars), consts, valid))
+    return [(ctypes.c_double * 4)(*consts[4 * a:4 * a + 4]) if valid[a] else None for a in range(3)]
+
+
+def _fc_arg(grid, pack, sp):
+    """the h_face_consts argument for a sweep of `pack` under the `sparse` word `sp`: only with sparse reads (fresh packs)"""
+    fc = getattr(pack, 'face_consts', None)
+    return fc if (fc is not None and (sp & 1)) else None
 
 
 def precompute_coeff_packs_unified(grid, mat, dir_mask=None, dir_value=None, neumann=None,
@@ -489,9 +508,12 @@ def precompute_coeff_packs_unified(grid, mat, dir_mask=None, dir_value=None, neu
             d_dv = L.to_layout(dir_value, torch.float64)
     packs = tuple(AxisCoeffPack(coeff[a], d_dm, d_dv, qflux[a], _has_dir=has_dir, _has_q=has_q, _layout=L)
                   for a in range(3))
+    fcs = _face_constants(grid, mat, [s[0] for s in h_specs], [s[1] for s in h_specs], [s[0] for s in q_specs],
+                          [s[1] for s in q_specs])
     for a, p in enumerate(packs):
         p.mask_version = grid.mask_version
         p.sparse_ok = True
+        p.face_consts = fcs[a]                           # per-face scalars: the sweeps need not load coeff / qflux
         p._fractions = (grid, a, grid.mask_version)      # exposed / Dirichlet fractions: evaluated when somebody asks
     return packs
 
@@ -590,7 +612,7 @@ def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None, 
                         _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
                         sp | nf.bit, params.theta,
                         gam, params.dt, float(Tinf), _p(t_out),
-                        _p(xlo), _p(xhi),
+                        _p(xlo), _p(xhi), _fc_arg(grid, pack, sp),
                         _p(work), wb, _stream()))
     nf.learn()
 
@@ -619,7 +641,7 @@ def _explicit_sweep0_into(t, t_out, grid, mat, params, pack, Tinf, variant=None,
     check(lib.adi_explicit_sweep0(v, _p(t), vlo, vhi, _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
                                   _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
                                   sp | nf.bit, grid.dx, params.dt, kappa, params.theta,
-                                  float(Tinf), _p(t_out), None, None, _p(work), wb, _stream()))
+                                  float(Tinf), _p(t_out), None, None, _fc_arg(grid, pack, sp), _p(work), wb, _stream()))
     nf.learn()
 
 
@@ -774,8 +796,10 @@ class BirthPacks:
         has_q = any(q[0] != _lib.FACE_NONE for q in qs)
         self.packs = tuple(AxisCoeffPack(self.coeff[a], None, None, self.qflux[a], _has_dir=False, _has_q=has_q, _layout=L)
                            for a in range(3))
-        for p in self.packs:
+        fcs = _face_constants(grid, mat, [h[0] for h in hs], [h[1] for h in hs], [q[0] for q in qs], [q[1] for q in qs])
+        for a, p in enumerate(self.packs):
             p.sparse_ok = True
+            p.face_consts = fcs[a]
         self.update(0, grid.nz)
 
     def update(self, k_begin, k_end):

@@ -27,11 +27,21 @@ int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, long plane_strid
     *bytes = nn[axis] > kMaxFastLine ? (size_t)2 * nx * L.sx * sizeof(double) : (cells / 8 + 64) * sizeof(unsigned);
     return ADI_OK;
 }
+// h_face_consts of the sweep entry points: (c-, c+, q-, q+) of the sweep axis for packs built from per-face scalars
+// (adi_face_constants); honoured only together with sparse reads -- stale or hand-built packs are read from their arrays
+static void set_face_consts(SweepScal &s, const double *fcs)
+{
+    if (fcs != nullptr && s.sparse) {
+        s.fconst = 1;
+        for (int i = 0; i < 4; ++i) s.fc[i] = fcs[i];
+    }
+}
+
 static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
                        const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
                        long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
                        const double *d_xlo, const double *d_xhi, void *d_work, size_t work_bytes, void *stream,
-                       const Fuse *fz, const double *c_lo = nullptr, const double *c_hi = nullptr,
+                       const Fuse *fz, const double *fcs, const double *c_lo = nullptr, const double *c_hi = nullptr,
                        const double *c_w = nullptr)
 {
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep: bad axis %d", axis);
@@ -52,6 +62,8 @@ static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t 
     s.sparse = (sparse & 1) ? 1 : 0;
     s.box = (sparse & 2) ? 1 : 0;
     s.nofb = (sparse & 4) ? 1 : 0;
+    if (s.tg < kMixedMinTg) s.sparse = 0;   // a vanishing time step: GENERAL kernels only (mixed_condense's recurrence would overflow)
+    set_face_consts(s, fcs);
     if (c_w != nullptr && (c_lo != nullptr || c_hi != nullptr)) {
         // deferred interface correction (adi_sweep_corrected): the strided kernels of memory axis 1 add it to what they load
         ADI_REQUIRE(axis == 1 && fz == nullptr && !d_xlo && !d_xhi, "adi_sweep_corrected: axis 1 sweeps only");
@@ -86,22 +98,24 @@ static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t 
 int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
               const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
               long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
-              const double *d_xlo, const double *d_xhi, void *d_work, size_t work_bytes, void *stream)
+              const double *d_xlo, const double *d_xhi, const double *h_face_consts, void *d_work, size_t work_bytes,
+              void *stream)
 {
     return sweep_entry(axis, variant, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
-                       sparse, theta, gam, dt, Tinf, d_out, d_xlo, d_xhi, d_work, work_bytes, stream, nullptr);
+                       sparse, theta, gam, dt, Tinf, d_out, d_xlo, d_xhi, d_work, work_bytes, stream, nullptr,
+                       h_face_consts);
 }
 
 int adi_sweep_corrected(int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
                         const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
                         long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
-                        const double *d_ulo, const double *d_uhi, const double *d_w, void *d_work, size_t work_bytes,
-                        void *stream)
+                        const double *d_ulo, const double *d_uhi, const double *d_w, const double *h_face_consts,
+                        void *d_work, size_t work_bytes, void *stream)
 {
     ADI_REQUIRE(d_w != nullptr || (d_ulo == nullptr && d_uhi == nullptr), "adi_sweep_corrected: interface values without weights");
     return sweep_entry(1, variant, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
-                       sparse, theta, gam, dt, Tinf, d_out, nullptr, nullptr, d_work, work_bytes, stream, nullptr, d_ulo,
-                       d_uhi, d_w);
+                       sparse, theta, gam, dt, Tinf, d_out, nullptr, nullptr, d_work, work_bytes, stream, nullptr,
+                       h_face_consts, d_ulo, d_uhi, d_w);
 }
 
 static Fuse make_fuse(int nx, int ny, int nz, long plane_stride, double dx, double dt, double kappa, double theta,
@@ -144,19 +158,19 @@ int adi_explicit_sweep0(int variant, const double *d_T, long valid_lo, long vali
                         const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
                         const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse, double dx,
                         double dt, double kappa, double theta, double Tinf, double *d_out, const double *d_xlo,
-                        const double *d_xhi, void *d_work, size_t work_bytes, void *stream)
+                        const double *d_xhi, const double *h_face_consts, void *d_work, size_t work_bytes, void *stream)
 {
     ADI_REQUIRE(valid_lo <= 0 && valid_hi >= (long)(nx - 1) * (plane_stride ? plane_stride : (long)ny * nz) + (long)ny * nz,
                 "adi_explicit_sweep0: the readable range [%ld, %ld) does not cover the box", valid_lo, valid_hi);
     const Fuse fz = make_fuse(nx, ny, nz, plane_stride, dx, dt, kappa, theta, valid_lo, valid_hi);
     const double gam = kappa * dt / (dx * dx);   // adi3d_numba_coeff.py:292
     return sweep_entry(0, variant, d_T, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
-                       sparse, theta, gam, dt, Tinf, d_out, d_xlo, d_xhi, d_work, work_bytes, stream, &fz);
+                       sparse, theta, gam, dt, Tinf, d_out, d_xlo, d_xhi, d_work, work_bytes, stream, &fz, h_face_consts);
 }
 static int condense_entry(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
                           const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny,
                           int nz, long plane_stride, int sparse, double theta, double gam, double dt, double Tinf,
-                          double *d_cond, void *d_work, size_t work_bytes, void *stream, const Fuse *fz)
+                          double *d_cond, void *d_work, size_t work_bytes, void *stream, const Fuse *fz, const double *fcs)
 {
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep_condense: bad axis %d", axis);
     bool has_dir, has_q;
@@ -173,6 +187,8 @@ static int condense_entry(int axis, int variant, const double *d_in, const uint8
     s.sparse = (sparse & 1) ? 1 : 0;
     s.box = (sparse & 2) ? 1 : 0;
     s.nofb = (sparse & 4) ? 1 : 0;
+    if (s.tg < kMixedMinTg) s.sparse = 0;   // (as in sweep_entry)
+    set_face_consts(s, fcs);
     hipStream_t st = as_stream(stream);
     SweepArgs a;
     a.in = d_in; a.flags = d_flags; a.coeff = d_coeff;
@@ -185,17 +201,17 @@ static int condense_entry(int axis, int variant, const double *d_in, const uint8
 int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
                        const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny,
                        int nz, long plane_stride, int sparse, double theta, double gam, double dt, double Tinf,
-                       double *d_cond, void *d_work, size_t work_bytes, void *stream)
+                       double *d_cond, const double *h_face_consts, void *d_work, size_t work_bytes, void *stream)
 {
     return condense_entry(axis, variant, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
-                          sparse, theta, gam, dt, Tinf, d_cond, d_work, work_bytes, stream, nullptr);
+                          sparse, theta, gam, dt, Tinf, d_cond, d_work, work_bytes, stream, nullptr, h_face_consts);
 }
 
 int adi_explicit_condense0(int variant, const double *d_T, long valid_lo, long valid_hi, const uint8_t *d_flags,
                            const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
                            const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse, double dx,
                            double dt, double kappa, double theta, double Tinf, double *d_cond, double *d_R0_out,
-                           void *d_work, size_t work_bytes, void *stream)
+                           const double *h_face_consts, void *d_work, size_t work_bytes, void *stream)
 {
     ADI_REQUIRE(valid_lo <= 0 && valid_hi >= (long)(nx - 1) * (plane_stride ? plane_stride : (long)ny * nz) + (long)ny * nz,
                 "adi_explicit_condense0: the readable range [%ld, %ld) does not cover the box", valid_lo, valid_hi);
@@ -204,7 +220,7 @@ int adi_explicit_condense0(int variant, const double *d_T, long valid_lo, long v
     fz.r0_out = d_R0_out;
     const double gam = kappa * dt / (dx * dx);
     return condense_entry(0, variant, d_T, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
-                          sparse, theta, gam, dt, Tinf, d_cond, d_work, work_bytes, stream, &fz);
+                          sparse, theta, gam, dt, Tinf, d_cond, d_work, work_bytes, stream, &fz, h_face_consts);
 }
 }  // extern "C"
 
@@ -213,10 +229,11 @@ int adi_explicit_condense0(int variant, const double *d_T, long valid_lo, long v
 static int step_impl(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b, const uint8_t *d_flags,
                      const double *const *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
                      const double *const *d_qflux, int variant, int sparse, int nx, int ny, int nz, long plane_stride,
-                     double dx, double rho, double cp, double k, double dt, double theta, double Tinf, void *d_work,
-                     size_t work_bytes, void *stream, unsigned *h_queued)
+                     double dx, double rho, double cp, double k, double dt, double theta, double Tinf,
+                     const double *h_face_consts, void *d_work, size_t work_bytes, void *stream, unsigned *h_queued)
 {
     ADI_REQUIRE(d_T_in && d_T_out && d_tmp_a && d_tmp_b && d_coeff, "adi_step: null argument");
+    const double *fc0 = h_face_consts, *fc1 = h_face_consts ? h_face_consts + 4 : nullptr, *fc2 = h_face_consts ? h_face_consts + 8 : nullptr;
     ADI_REQUIRE(d_tmp_a != d_tmp_b && d_tmp_a != d_T_in && d_tmp_b != d_T_in && d_T_out != d_tmp_a && d_T_out != d_T_in,
                 "adi_step: buffers must be distinct (T_out may equal tmp_b only)");
     // kappa, gam: adi3d_numba_coeff.py:292
@@ -243,20 +260,20 @@ static int step_impl(const double *d_T_in, double *d_T_out, double *d_tmp_a, dou
         const long sxe = plane_stride ? plane_stride : (long)ny * nz;
         rc = adi_explicit_sweep0(variant, d_T_in, 0, (long)(nx - 1) * sxe + (long)ny * nz, d_flags, d_coeff[0], d_dir_mask,
                                  d_dir_val, q0, nx, ny, nz, plane_stride, sparse, dx, dt, kappa, theta, Tinf, d_tmp_b,
-                                 nullptr, nullptr, d_work, work_bytes, stream);
+                                 nullptr, nullptr, fc0, d_work, work_bytes, stream);
     } else {
         rc = adi_explicit_rhs(d_T_in, d_flags, nx, ny, nz, plane_stride, dx, dt, kappa, theta, d_tmp_a, stream);
         if (rc) return rc;
-        rc = adi_sweep(0, variant, d_tmp_a, d_flags, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_b, nullptr, nullptr, d_work, work_bytes, stream);
+        rc = adi_sweep(0, variant, d_tmp_a, d_flags, d_coeff[0], d_dir_mask, d_dir_val, q0, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_b, nullptr, nullptr, fc0, d_work, work_bytes, stream);
     }
     if (rc) return rc;
     report(0);
     arm(1);
-    rc = adi_sweep(1, variant, d_tmp_b, d_flags, d_coeff[1], d_dir_mask, d_dir_val, q1, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_a, nullptr, nullptr, d_work, work_bytes, stream);
+    rc = adi_sweep(1, variant, d_tmp_b, d_flags, d_coeff[1], d_dir_mask, d_dir_val, q1, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_tmp_a, nullptr, nullptr, fc1, d_work, work_bytes, stream);
     if (rc) return rc;
     report(1);
     arm(2);
-    rc = adi_sweep(2, variant, d_tmp_a, d_flags, d_coeff[2], d_dir_mask, d_dir_val, q2, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_T_out, nullptr, nullptr, d_work, work_bytes, stream);
+    rc = adi_sweep(2, variant, d_tmp_a, d_flags, d_coeff[2], d_dir_mask, d_dir_val, q2, nx, ny, nz, plane_stride, sparse, theta, gam, dt, Tinf, d_T_out, nullptr, nullptr, fc2, d_work, work_bytes, stream);
     if (rc) return rc;
     report(2);
     return ADI_OK;
@@ -267,23 +284,23 @@ extern "C" {
 int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b, const uint8_t *d_flags,
              const double *const *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
              const double *const *d_qflux, int variant, int sparse, int nx, int ny, int nz, long plane_stride,
-             double dx, double rho, double cp, double k, double dt, double theta, double Tinf, void *d_work,
-             size_t work_bytes, void *stream)
+             double dx, double rho, double cp, double k, double dt, double theta, double Tinf,
+             const double *h_face_consts, void *d_work, size_t work_bytes, void *stream)
 {
     return step_impl(d_T_in, d_T_out, d_tmp_a, d_tmp_b, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, variant, sparse, nx, ny,
-                     nz, plane_stride, dx, rho, cp, k, dt, theta, Tinf, d_work, work_bytes, stream, nullptr);
+                     nz, plane_stride, dx, rho, cp, k, dt, theta, Tinf, h_face_consts, d_work, work_bytes, stream, nullptr);
 }
 
 int adi_step_queued(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_tmp_b, const uint8_t *d_flags,
                     const double *const *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
                     const double *const *d_qflux, int variant, int sparse, int nx, int ny, int nz, long plane_stride,
-                    double dx, double rho, double cp, double k, double dt, double theta, double Tinf, void *d_work,
-                    size_t work_bytes, void *stream, unsigned *h_queued)
+                    double dx, double rho, double cp, double k, double dt, double theta, double Tinf,
+                    const double *h_face_consts, void *d_work, size_t work_bytes, void *stream, unsigned *h_queued)
 {
     ADI_REQUIRE(h_queued && d_work && work_bytes >= sizeof(unsigned), "adi_step_queued: needs a workspace and three host words");
     ADI_REQUIRE((sparse & 4) == 0, "adi_step_queued: the no-fallback promise skips the queue it is asked to report");
     h_queued[0] = h_queued[1] = h_queued[2] = 0xffffffffu;
     return step_impl(d_T_in, d_T_out, d_tmp_a, d_tmp_b, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, variant, sparse, nx, ny,
-                     nz, plane_stride, dx, rho, cp, k, dt, theta, Tinf, d_work, work_bytes, stream, h_queued);
+                     nz, plane_stride, dx, rho, cp, k, dt, theta, Tinf, h_face_consts, d_work, work_bytes, stream, h_queued);
 }
 }  // extern "C"

@@ -74,7 +74,44 @@ struct SweepScal {
     const double *c_lo = nullptr, *c_hi = nullptr, *c_w = nullptr;
     int c_n = 0;
     unsigned c_bytes = 0;   // bytes of a correction plane (the range of the buffer descriptors over c_lo / c_hi)
+    // Packs built from per-face SCALARS (h_face_consts of the sweep entry points; only with `sparse`): the Robin coefficient /
+    // Neumann flux of a cell exposed along the sweep axis is  (0 + [minus neighbour missing] fc[0]) + [plus neighbour missing]
+    // fc[1]  (flux: fc[2], fc[3]) -- the accumulation order of precompute_coeff_packs_unified (adi3d_numba_coeff.py:93-114),
+    // so the value is the one stored in the pack array, bit for bit -- and follows from the flags byte alone.  The kernels
+    // then do not load coeff / qflux at all: on a curved solid those loads can only be issued once the flags have arrived, a
+    // second memory latency in every wave that holds a surface row (512^3 ellipsoid: 6 % of the step).
+    int fconst = 0;
+    double fc[4] = {0.0, 0.0, 0.0, 0.0};
 };
+
+// Coefficient / flux of an in-mask cell that is exposed along the sweep axis: from the flags (per-face scalars, see
+// SweepScal::fconst) or from the pack array.  has_lo / has_hi: the minus / plus neighbour along the axis is in the mask.
+// FCM: 0 = decided at run time (s.fconst), 1 = always from the flags, 2 = always from the array.  The strided FAST kernels
+// are instantiated both ways (a template parameter, adi_sweep_strided_fc.hip): with the choice made at run time the mere
+// presence of the load path cost the 512^3 ellipsoid 0.02 ms in each of the two strided sweeps.
+template <int FCM = 0>
+__device__ __forceinline__ double pack_co(const SweepScal &s, const double *p, bool has_lo, bool has_hi)
+{
+    if (FCM == 1 || (FCM == 0 && s.fconst)) {
+        double co = 0.0;
+        if (!has_lo) co += s.fc[0];
+        if (!has_hi) co += s.fc[1];
+        return co;
+    }
+    return *p;
+}
+template <bool HAS_Q, int FCM = 0>
+__device__ __forceinline__ double pack_q(const SweepScal &s, const double *p, bool has_lo, bool has_hi)
+{
+    if (!HAS_Q) return 0.0;
+    if (FCM == 1 || (FCM == 0 && s.fconst)) {
+        double q = 0.0;
+        if (!has_lo) q += s.fc[2];
+        if (!has_hi) q += s.fc[3];
+        return q;
+    }
+    return *p;
+}
 
 // cell is in the mask and lacks at least one in-mask neighbour along the sweep axis: the only cells where
 // precompute_coeff_packs_unified writes a Robin coefficient or a Neumann flux for that axis (:93-99, :104-114)
@@ -198,7 +235,7 @@ __device__ __forceinline__ void assemble_row(bool m, bool mL, bool mR, bool dir,
 // 0 in coeff / qflux (rows `rstride` elements apart).  On entry d = the incoming values with rows 0 and M-1 already
 // assembled (a0, b0 belong to row 0); on exit d[modified row] = its assembled right-hand side, bmod = its diagonal and
 // k = the segment's condensation.
-template <int M, bool HAS_Q, class UC>
+template <int M, bool HAS_Q, int FCM = 0, class UC>
 __device__ __forceinline__ void mixed_lane_condense(int kind, int L, const UC &U, const SweepScal &s,
                                                     const double *__restrict__ coeff0, const double *__restrict__ qf0,
                                                     long rstride, double a0, double b0, double (&d)[M], double2 &bm,
@@ -212,7 +249,7 @@ __device__ __forceinline__ void mixed_lane_condense(int kind, int L, const UC &U
         bm.x = b0;
         if (e1 > 1) {
             const int rm = e1 - 1;
-            const double co = coeff0[(long)rm * rstride], q = HAS_Q ? qf0[(long)rm * rstride] : 0.0;
+            const double co = pack_co<FCM>(s, coeff0 + (long)rm * rstride, true, false), q = pack_q<HAS_Q, FCM>(s, qf0 + (long)rm * rstride, true, false);
             double din = 0.0, am, cm, dm;
 #pragma unroll
             for (int r = 1; r < MI; ++r) din = (r == rm) ? d[r] : din;
@@ -225,7 +262,7 @@ __device__ __forceinline__ void mixed_lane_condense(int kind, int L, const UC &U
         bm.y = 1.0;
         if (L2 >= 1) {
             const int rm = MI - L2;
-            const double co = coeff0[(long)rm * rstride], q = HAS_Q ? qf0[(long)rm * rstride] : 0.0;
+            const double co = pack_co<FCM>(s, coeff0 + (long)rm * rstride, false, true), q = pack_q<HAS_Q, FCM>(s, qf0 + (long)rm * rstride, false, true);
             double din = 0.0, am, cm, dm;
 #pragma unroll
             for (int r = 1; r < MI; ++r) din = (r == rm) ? d[r] : din;
@@ -241,7 +278,7 @@ __device__ __forceinline__ void mixed_lane_condense(int kind, int L, const UC &U
         const int m = L >> 8, len = L & 255, e = m + len;
         double bS = b0, bE = U.bu;                          // a run that starts at row 0: fast_segment_ends assembled it
         if (m >= 1) {
-            const double co = coeff0[(long)m * rstride], q = HAS_Q ? qf0[(long)m * rstride] : 0.0;
+            const double co = pack_co<FCM>(s, coeff0 + (long)m * rstride, false, len > 1), q = pack_q<HAS_Q, FCM>(s, qf0 + (long)m * rstride, false, len > 1);
             double din = 0.0, am, cm, dm;
 #pragma unroll
             for (int r = 1; r < MI; ++r) din = (r == m) ? d[r] : din;
@@ -250,7 +287,7 @@ __device__ __forceinline__ void mixed_lane_condense(int kind, int L, const UC &U
             for (int r = 1; r < MI; ++r) d[r] = (r == m) ? dm : d[r];
         }
         if (len > 1) {
-            const double co = coeff0[(long)(e - 1) * rstride], q = HAS_Q ? qf0[(long)(e - 1) * rstride] : 0.0;
+            const double co = pack_co<FCM>(s, coeff0 + (long)(e - 1) * rstride, true, false), q = pack_q<HAS_Q, FCM>(s, qf0 + (long)(e - 1) * rstride, true, false);
             double din = 0.0, am, cm, dm;
 #pragma unroll
             for (int r = 1; r < MI; ++r) din = (r == e - 1) ? d[r] : din;
@@ -268,8 +305,8 @@ __device__ __forceinline__ void mixed_lane_condense(int kind, int L, const UC &U
     const int rmod = tail ? MI - L : L - 1;                 // the line-start / line-end row of the run
     bmod = b0;                                              // head run of one row: row 0 is that row, already assembled
     if (L >= 1 && (tail || rmod > 0)) {
-        const double co = coeff0[(long)rmod * rstride];     // exposed along the axis: carries the Robin coefficient
-        const double q = HAS_Q ? qf0[(long)rmod * rstride] : 0.0;
+        const double co = pack_co<FCM>(s, coeff0 + (long)rmod * rstride, !tail, tail);   // exposed along the axis: carries the Robin coefficient
+        const double q = pack_q<HAS_Q, FCM>(s, qf0 + (long)rmod * rstride, !tail, tail);
         double din = 0.0;
 #pragma unroll
         for (int r = 1; r < MI; ++r) din = (r == rmod) ? d[r] : din;
@@ -457,7 +494,7 @@ __device__ __forceinline__ double row_bcast(double v, int r)
 }
 
 // part 2: the two general rows of a uniform segment (row 0 and the separator)
-template <int M, bool HAS_DIR, bool HAS_Q>
+template <int M, bool HAS_DIR, bool HAS_Q, int FCM = 0>
 __device__ __forceinline__ void fast_segment_ends(const double *__restrict__ coeff, const double *__restrict__ dval,
                                                   const double *__restrict__ qf, const LineGeom &g, long base, int r0,
                                                   unsigned f0, unsigned fS, bool dirS, const SweepScal &s,
@@ -466,9 +503,10 @@ __device__ __forceinline__ void fast_segment_ends(const double *__restrict__ coe
 {
     const long p0 = base + (long)r0 * g.stride, pS = base + (long)(r0 + M - 1) * g.stride;
     const bool e0 = axis_exposed(f0, g.lbit), eS = axis_exposed(fS, g.lbit);
-    const double co0 = e0 ? coeff[p0] : 0.0, coS = eS ? coeff[pS] : 0.0;
+    const bool l0 = (f0 >> g.lbit) & 1u, h0 = (f0 >> (g.lbit + 1)) & 1u, lS = (fS >> g.lbit) & 1u, hS = (fS >> (g.lbit + 1)) & 1u;
+    const double co0 = e0 ? pack_co<FCM>(s, coeff + p0, l0, h0) : 0.0, coS = eS ? pack_co<FCM>(s, coeff + pS, lS, hS) : 0.0;
     double q0 = 0.0, qS = 0.0, dvS = 0.0;
-    if (HAS_Q) { q0 = e0 ? qf[p0] : 0.0; qS = eS ? qf[pS] : 0.0; }
+    if (HAS_Q) { q0 = e0 ? pack_q<HAS_Q, FCM>(s, qf + p0, l0, h0) : 0.0; qS = eS ? pack_q<HAS_Q, FCM>(s, qf + pS, lS, hS) : 0.0; }
     if (HAS_DIR) dvS = dirS ? dval[pS] : 0.0;
     double c0;
     assemble_row<HAS_DIR, HAS_Q>(f0 & 1u, (f0 >> g.lbit) & 1u, (f0 >> (g.lbit + 1)) & 1u, false, d[0], co0, 0.0, q0, s,

@@ -76,7 +76,11 @@ inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok,
             // n = 512 (16 segments: 256-thread workgroups, four per CU instead of two): axis 1 of 512^3 0.424 -> 0.414 ms
             mf = 32; lf = 16;
         } else {
-            const int m2 = (n > 256) ? 16 : 8;
+            // 16 rows per thread from 160 rows where 16 divides the line (round 3, scripts/perf_map_small.py: with 8 rows a
+            // 256-row line spread its interface solve over 32 lanes and the tile over 512 threads -- 256^3: fused kernel
+            // 131 -> 159 Gcell/s, axis 1 226 -> 259, step 0.261 -> 0.230 ms; 160 / 192 / 224 rows along axis 0: 96 / 107 /
+            // 120 -> 131 / 153 / 159 Gcell/s); beyond 256 rows always (as before: no FAST kernel when 16 does not divide)
+            const int m2 = (n > 256 || (n >= 160 && n % 16 == 0)) ? 16 : 8;
             if (n % m2 == 0 && n / m2 <= 64) { mf = m2; lf = (16 * next_pow2(n / m2) > 512) ? 8 : 16; }
         }
         if (mf) {

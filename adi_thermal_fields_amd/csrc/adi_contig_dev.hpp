@@ -114,9 +114,11 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     else load_rows_contig<M, VEC>(in, base, r0, n, active, d);
     // the two ends of a line are always exposed: fetch their coefficient / flux with the first batch of loads
     const bool sp0 = active && li == 0, spS = active && (r0 + M == n);
-    const double co0s = sp0 ? coeff[base] : 0.0, coSs = spS ? coeff[base + M - 1] : 0.0;
+    // (per-face scalars, SweepScal::fconst: nothing is loaded, the values follow from the flags below)
+    const bool ldc = !s.fconst;
+    const double co0s = (ldc && sp0) ? coeff[base] : 0.0, coSs = (ldc && spS) ? coeff[base + M - 1] : 0.0;
     double q0s = 0.0, qSs = 0.0;
-    if (HAS_Q) { q0s = sp0 ? qf[base] : 0.0; qSs = spS ? qf[base + M - 1] : 0.0; }
+    if (HAS_Q) { q0s = (ldc && sp0) ? qf[base] : 0.0; qSs = (ldc && spS) ? qf[base + M - 1] : 0.0; }
     // padding lanes (beyond the end of a line whose segment count is not a power of two, or beyond the last line)
     // own no rows: they never force the unit to the GENERAL kernel, export an identity block and store nothing
     const bool pad = !active || r0 >= n;
@@ -146,9 +148,14 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     }
     // row 0 and the separator row are general rows; only they can carry a coefficient / flux / Dirichlet value
     const bool e0 = axis_exposed(fb[0], 5), eS = axis_exposed(fb[M - 1], 5);
-    const double co0 = e0 ? (sp0 ? co0s : coeff[base]) : 0.0, coS = eS ? (spS ? coSs : coeff[base + M - 1]) : 0.0;
+    const bool l0 = (fb[0] >> 5) & 1u, h0 = (fb[0] >> 6) & 1u, lS = (fb[M - 1] >> 5) & 1u, hS = (fb[M - 1] >> 6) & 1u;
+    const double co0 = e0 ? ((ldc && sp0) ? co0s : pack_co(s, coeff + base, l0, h0)) : 0.0;
+    const double coS = eS ? ((ldc && spS) ? coSs : pack_co(s, coeff + base + M - 1, lS, hS)) : 0.0;
     double q0 = 0.0, qS = 0.0, dvS = 0.0;
-    if (HAS_Q) { q0 = e0 ? (sp0 ? q0s : qf[base]) : 0.0; qS = eS ? (spS ? qSs : qf[base + M - 1]) : 0.0; }
+    if (HAS_Q) {
+        q0 = e0 ? ((ldc && sp0) ? q0s : pack_q<HAS_Q>(s, qf + base, l0, h0)) : 0.0;
+        qS = eS ? ((ldc && spS) ? qSs : pack_q<HAS_Q>(s, qf + base + M - 1, lS, hS)) : 0.0;
+    }
     const bool dirS = HAS_DIR && db[M - 1] != 0;
     if (HAS_DIR) dvS = dirS ? dval[base + M - 1] : 0.0;
     double a0, b0, c0, aS, bS, cS;

@@ -43,6 +43,8 @@ struct adi_ctx {
     bool have_mask, have_packs, have_T;
     bool all_solid;      // every cell in the mask: passed to adi_step as the box hint (bit 1 of `sparse`)
     int promise;         // no-fallback promise (bit 2 of `sparse`): -1 not known for this mask / these packs, 0 no, 1 yes
+    double fconsts[12];  // per-face scalar coefficients / fluxes of the packs (adi_face_constants) ...
+    bool fconsts_ok;     // ... valid for all three axes: passed to adi_step as h_face_consts
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     float last_ms;
@@ -200,6 +202,11 @@ int adi_ctx_build_coeffs(adi_ctx *c, double rho, double cp, const int *h_mode, c
     if (rc == ADI_OK)
         rc = adi_build_coeffs(c->mask, c->nx, c->ny, c->nz, c->sx, c->dx, rho, cp, h_mode, h_scalar, dh, q_mode, q_scalar, dq,
                               c->coeff, c->qflux, c->stream);
+    if (rc == ADI_OK) {
+        int valid[3];
+        rc = adi_face_constants(c->dx, rho, cp, h_mode, h_scalar, q_mode, q_scalar, c->fconsts, valid);
+        c->fconsts_ok = rc == ADI_OK && valid[0] && valid[1] && valid[2];
+    }
     bool has_dir = false, has_q = false;
     if (rc == ADI_OK) {
         for (int f = 0; f < 6; ++f) has_q = has_q || (q_mode[f] != ADI_FACE_NONE);
@@ -276,14 +283,14 @@ int adi_ctx_step(adi_ctx *c, double rho, double cp, double k, double dt, double 
             unsigned q[3];
             rc = adi_step_queued(c->T[c->cur], c->T[nxt], c->tmp[0], c->tmp[1], c->flags, c->coeff, c->dir_mask, c->dir_val,
                                  c->qflux, c->variant, sp, c->nx, c->ny, c->nz, c->sx, c->dx, rho, cp, k, dt, theta, Tinf,
-                                 c->work, c->work_bytes, c->stream, q);
+                                 c->fconsts_ok ? c->fconsts : nullptr, c->work, c->work_bytes, c->stream, q);
             if (rc != ADI_OK) return rc;
             ADI_HIP_TRY(hipStreamSynchronize(c->stream));
             c->promise = (q[0] == 0 && q[1] == 0 && q[2] == 0) ? 1 : 0;
         } else {
             rc = adi_step(c->T[c->cur], c->T[nxt], c->tmp[0], c->tmp[1], c->flags, c->coeff, c->dir_mask, c->dir_val, c->qflux,
                           c->variant, sp | (c->promise == 1 ? 4 : 0), c->nx, c->ny, c->nz, c->sx, c->dx, rho, cp, k, dt, theta, Tinf,
-                          c->work, c->work_bytes, c->stream);
+                          c->fconsts_ok ? c->fconsts : nullptr, c->work, c->work_bytes, c->stream);
             if (rc != ADI_OK) return rc;
         }
         c->cur = nxt;

@@ -763,8 +763,8 @@ static int cyl_sweep_phi(const adi_cyl_plan *pl, const double *in, double *out, 
     const int nr = pl->nr, nphi = pl->nphi, nz = pl->nz;
     if (pl->phi_M && nz % 32 == 0) {
         const int M = pl->phi_M, Lp = nphi / M;
-        int lines = 32;                                   // 256-byte row pieces
-        while (lines * Lp > 1024) lines >>= 1;
+        int lines = 32;                                   // 256-byte row pieces (64-line tiles, one wave per segment and the
+        while (lines * Lp > 1024) lines >>= 1;            // Sherman-Morrison vector by scalar loads: 62.7 us against 55.6)
         const int tiles_inner = nz / lines;
         const long ntiles = (long)tiles_inner * nr;
         const size_t lds = (size_t)7 * lines * (Lp + 1) * sizeof(double);

@@ -506,6 +506,27 @@ int adi_build_coeffs_planes(const uint8_t *d_mask, int nx, int ny, int nz, long 
     return ADI_OK;
 }
 
+int adi_face_constants(double dx, double rho, double cp, const int *h_mode, const double *h_scalar, const int *q_mode,
+                       const double *q_scalar, double *h_consts, int *h_valid)
+{
+#pragma clang fp contract(off)
+    ADI_REQUIRE(h_mode && h_scalar && q_mode && q_scalar && h_consts && h_valid, "adi_face_constants: null argument");
+    // the very expressions of adi_build_coeffs_planes / k_build_coeffs: (h * A) / Ccell, IEEE, no contraction
+    const double A = dx * dx, V = pow(dx, 3.0), Ccell = rho * cp * V;
+    for (int a = 0; a < 3; ++a) {
+        bool ok = true;
+        for (int s = 0; s < 2; ++s) {
+            const int f = 2 * a + s;
+            ADI_REQUIRE(h_mode[f] >= 0 && h_mode[f] <= 2 && q_mode[f] >= 0 && q_mode[f] <= 2, "adi_face_constants: bad face mode");
+            ok = ok && h_mode[f] != ADI_FACE_FIELD && q_mode[f] != ADI_FACE_FIELD;
+            h_consts[4 * a + s] = (h_mode[f] == ADI_FACE_SCALAR) ? (h_scalar[f] * A / Ccell) : 0.0;
+            h_consts[4 * a + 2 + s] = (q_mode[f] == ADI_FACE_SCALAR) ? (q_scalar[f] * A / Ccell) : 0.0;
+        }
+        h_valid[a] = ok ? 1 : 0;
+    }
+    return ADI_OK;
+}
+
 int adi_build_coeffs(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, double dx, double rho,
                      double cp, const int *h_mode, const double *h_scalar, const double *const *d_h_field,
                      const int *q_mode, const double *q_scalar, const double *const *d_q_field,

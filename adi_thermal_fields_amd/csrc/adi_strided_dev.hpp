@@ -79,8 +79,9 @@ __device__ __forceinline__ void load_segment_raw(
         const bool need = ok && (!s.sparse || axis_exposed(R.fb[r], g.lbit));
         R.dirb[r] = false;
         if (HAS_DIR) R.dirb[r] = (bstrip != nullptr) ? (((dpk >> (8 * r)) & 0xffull) != 0) : (ok && dmask[p] != 0);
-        R.vco[r] = need ? coeff[p] : 0.0;
-        R.vq[r] = (HAS_Q && need) ? qf[p] : 0.0;
+        const bool hl = (R.fb[r] >> g.lbit) & 1u, hh = (R.fb[r] >> (g.lbit + 1)) & 1u;
+        R.vco[r] = need ? pack_co(s, coeff + p, hl, hh) : 0.0;                     // (fconst only comes with sparse)
+        R.vq[r] = (HAS_Q && need) ? pack_q<HAS_Q>(s, qf + p, hl, hh) : 0.0;
         R.vdv[r] = (HAS_DIR && ok && (!s.sparse || R.dirb[r])) ? dval[p] : 0.0;
     }
 }
@@ -188,8 +189,14 @@ __device__ __forceinline__ void load_segment_raw_buf(
             R.dirb[r] = false;
             if (HAS_DIR) R.dirb[r] = (bstrip != nullptr || bstrip16 != nullptr) ? (((dpk >> (8 * r)) & 0xffull) != 0)
                                                          : (__builtin_amdgcn_raw_buffer_load_b8(rM, voff, (unsigned)r * st, 0) != 0);
-            R.vco[r] = need ? buf_load_f64(rC, vb, (unsigned)r * st8) : 0.0;
-            R.vq[r] = (HAS_Q && need) ? buf_load_f64(rQ, vb, (unsigned)r * st8) : 0.0;
+            if (s.fconst) {
+                const bool hl = (R.fb[r] >> g.lbit) & 1u, hh = (R.fb[r] >> (g.lbit + 1)) & 1u;
+                R.vco[r] = need ? pack_co(s, nullptr, hl, hh) : 0.0;
+                R.vq[r] = (HAS_Q && need) ? pack_q<HAS_Q>(s, nullptr, hl, hh) : 0.0;
+            } else {
+                R.vco[r] = need ? buf_load_f64(rC, vb, (unsigned)r * st8) : 0.0;
+                R.vq[r] = (HAS_Q && need) ? buf_load_f64(rQ, vb, (unsigned)r * st8) : 0.0;
+            }
             R.vdv[r] = (HAS_DIR && R.dirb[r]) ? buf_load_f64(rV, vb, (unsigned)r * st8) : 0.0;
         }
     }

@@ -7,7 +7,9 @@
 
 namespace adi {
 
-template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false, bool MIXED = true>
+// FC: the pack was built from per-face scalars (SweepScal::fconst): coefficient / flux of an exposed row from its flags,
+// no load path in the kernel at all (instantiated in adi_sweep_strided_fc.hip)
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false, bool MIXED = true, bool FC = false>
 __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_fast(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
             corr_apply<M>(s, corr_weights(s, to), (voff + (unsigned)(ti * LINES)) * 8u, (unsigned)(g.stride * 8), d);
     }
     double a0, b0, aS, bS, cS;
-    fast_segment_ends<M, HAS_DIR, HAS_Q>(coeff, dval, qf, g, base, r0, f0, fS, dirS, s, d, a0, b0, aS, bS, cS);
+    fast_segment_ends<M, HAS_DIR, HAS_Q, (FC ? 1 : 2)>(coeff, dval, qf, g, base, r0, f0, fS, dirS, s, d, a0, b0, aS, bS, cS);
     if (r0 == 0) {
         if (xlo != nullptr) d[0] = __builtin_fma(-a0, xlo[line_id], d[0]);
         a0 = 0.0;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
     double2 bmod = make_double2(1.0, 1.0);
     if constexpr (MIXED) {
         if (kind >= SEG_TAIL)                      // the surface crosses the segment once (adi_core.hpp, mixed_*)
-            mixed_lane_condense<M, HAS_Q>(kind, Lm, U, s, coeff + base + (long)r0 * g.stride,
+            mixed_lane_condense<M, HAS_Q, (FC ? 1 : 2)>(kind, Lm, U, s, coeff + base + (long)r0 * g.stride,
                                           HAS_Q ? qf + base + (long)r0 * g.stride : qf, g.stride, a0, b0, d, bmod, k);
     }
     double xL, xS;
@@ -128,20 +130,38 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
     }
 }
 
+template <int MF, bool HAS_DIR, bool HAS_Q, bool FUSE, bool FC>
+inline void launch_strided_fast_t(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
+                                  const uint8_t *dmask, const double *dval, const double *qf, double *out,
+                                  const LineGeom &g, const double *xlo, const double *xhi, SweepScal s, unsigned *queue,
+                                  hipStream_t st, const Fuse &fz)
+{
+    if (s.box && MF <= 16) // all-solid box (caller's hint): the build without surface-segment lanes (fused: no spills)
+        hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE, (MF > 16), FC>), dim3((unsigned)P.ntiles_f),
+                           dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
+                           P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
+    else
+        hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE, true, FC>), dim3((unsigned)P.ntiles_f),
+                           dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
+                           P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
+}
+
+// adi_sweep_strided_fc.hip: the FC = true instantiations (8 / 16 / 32 rows per thread, no Dirichlet cells, fused or not)
+void strided_fast_fc(int mf, bool has_q, bool fuse, const StridedPlan &P, const double *in, const uint8_t *flags,
+                     const double *coeff, const double *qf, double *out, const LineGeom &g, const double *xlo,
+                     const double *xhi, SweepScal s, unsigned *queue, hipStream_t st, const Fuse &fz);
+
 template <int MF, bool HAS_DIR, bool HAS_Q, bool FUSE>
 inline void launch_strided_fast(const StridedPlan &P, const double *in, const uint8_t *flags, const double *coeff,
                                 const uint8_t *dmask, const double *dval, const double *qf, double *out,
                                 const LineGeom &g, const double *xlo, const double *xhi, SweepScal s, unsigned *queue,
                                 hipStream_t st, const Fuse &fz)
 {
-    if (s.box && MF <= 16) // all-solid box (caller's hint): the build without surface-segment lanes (fused: no spills)
-        hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE, (MF > 16)>), dim3((unsigned)P.ntiles_f),
-                           dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
-                           P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
+    if (!HAS_DIR && s.fconst && (MF == 8 || MF == 16 || MF == 32))
+        strided_fast_fc(MF, HAS_Q, FUSE, P, in, flags, coeff, qf, out, g, xlo, xhi, s, queue, st, fz);
     else
-        hipLaunchKernelGGL((k_sweep_strided_fast<MF, HAS_DIR, HAS_Q, FUSE, true>), dim3((unsigned)P.ntiles_f),
-                           dim3(P.lines_f * P.Lpf), P.lds_f, st, in, flags, coeff, dmask, dval, qf, out, g, P.Lpf, P.lines_f,
-                           P.tiles_inner_f, P.ntiles_f, xlo, xhi, s, queue, make_unic<MF>(s.tg), fz);
+        launch_strided_fast_t<MF, HAS_DIR, HAS_Q, FUSE, false>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue,
+                                                               st, fz);
 }
 
 // adi_sweep_strided_x.hip: launch_strided_fast<mf, ..., false> for mf = 20, 24, 28

@@ -43,8 +43,17 @@ __device__ __forceinline__ void contig_unit_general(
             need = need || axis_exposed(fb[r], 5);
             if (HAS_DIR) needd = needd || (db[r] != 0);
         }
-        load_rows_contig<M, VEC>(coeff, base, r0, n, active && need, vco);
-        if (HAS_Q) load_rows_contig<M, VEC>(qf, base, r0, n, active && need, vq);
+        if (s.fconst) {                    // per-face scalars: coefficient / flux of the exposed cells from their flags
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+                const bool ex = axis_exposed(fb[r], 5), hl = (fb[r] >> 5) & 1u, hh = (fb[r] >> 6) & 1u;
+                vco[r] = ex ? pack_co(s, nullptr, hl, hh) : 0.0;
+                vq[r] = (HAS_Q && ex) ? pack_q<HAS_Q>(s, nullptr, hl, hh) : 0.0;
+            }
+        } else {
+            load_rows_contig<M, VEC>(coeff, base, r0, n, active && need, vco);
+            if (HAS_Q) load_rows_contig<M, VEC>(qf, base, r0, n, active && need, vq);
+        }
         if (HAS_DIR) load_rows_contig<M, VEC>(dval, base, r0, n, active && needd, vdv);
     }
     double a[M], b[M], c[M], d[M];

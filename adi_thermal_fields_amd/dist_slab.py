@@ -203,6 +203,7 @@ class HipEngine:
         self.box_hint = 0          # 2: every cell of every slab is in the mask (SlabStepper.set_mask decides, collectively)
         self.mask_epoch = 0        # bumped by SlabStepper.set_mask: the flags / packs are rebuilt in place
         self._nofb = {}            # no-fallback promise per sweep configuration (bit 2 of `sparse`, include/adi_hip.h)
+        self._fconsts = {}         # coefficient storage -> per-face scalars of the pack built on it (h_face_consts)
 
     def layout(self, nx, ny, nz, sx=None):
         return self.hip.Layout(nx, ny, nz, sx)
@@ -216,14 +217,21 @@ class HipEngine:
                                                 self.hip._stream()))
         return flags
 
+    def _fc(self, pack):
+        """h_face_consts of a pack tuple (coeff, dir_mask, dir_val, qflux) or of any view cut out of it: the per-face scalars
+        the pack was built from (registered by build_packs under the coefficient array's storage), or None"""
+        return self._fconsts.get(pack[0].untyped_storage().data_ptr())
+
     def build_packs(self, L, mask_ext, flags_ext, dx, mat, dir_mask, dir_value, neumann, robin_h):
         """precompute_coeff_packs_unified on the extended slab; returns packs whose arrays are extended too."""
         g = self.hip.Grid3D.__new__(self.hip.Grid3D)
         g.nx, g.ny, g.nz, g.dx, g.layout = L.nx, L.ny, L.nz, float(dx), L
         g._mask, g._d_mask, g._d_flags, g._scratch, g.mask_version = None, mask_ext, flags_ext, None, next(self.hip._MASK_VERSIONS)
         g.sync_mask = lambda: mask_ext            # the device mask (with halos) is authoritative here
-        return self.hip.precompute_coeff_packs_unified(g, mat, dir_mask=dir_mask, dir_value=dir_value,
-                                                       neumann=neumann, robin_h=robin_h)
+        packs = self.hip.precompute_coeff_packs_unified(g, mat, dir_mask=dir_mask, dir_value=dir_value,
+                                                        neumann=neumann, robin_h=robin_h)
+        self._fconsts = {p.d_coeff.untyped_storage().data_ptr(): p.face_consts for p in packs if p.face_consts is not None}
+        return packs
 
     def explicit(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin=0, i_end=None):
         h = self.hip
@@ -269,14 +277,14 @@ class HipEngine:
         key, bit = self._promise('sweep', axis, variant, Li, flags, pack)
         a = list(self._args(axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf))
         a[12] |= bit
-        self.check(self.lib.adi_sweep(*a, h._p(t_out), h._p(xlo), h._p(xhi), h._p(w), w.numel(), h._stream()))
+        self.check(self.lib.adi_sweep(*a, h._p(t_out), h._p(xlo), h._p(xhi), self._fc(pack), h._p(w), w.numel(), h._stream()))
         self._learn(key, w)
 
     def condense(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, cond):
         h = self.hip
         w = self._workspace(Li)
         self.check(self.lib.adi_sweep_condense(*self._args(axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf),
-                                               h._p(cond), h._p(w), w.numel(), h._stream()))
+                                               h._p(cond), self._fc(pack), h._p(w), w.numel(), h._stream()))
 
     # explicit stage folded into the axis-0 sweep / condensation (ABI v7).  The box (L.nx, L.ny, L.nz) starts at plane
     # i0, row j0 of the extended state T_ext; neighbours outside the box are read from T_ext itself.
@@ -296,7 +304,8 @@ class HipEngine:
         key, bit = self._promise('fused', 0, variant, L, flags, pack)
         a = list(self._fused_args(variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf))
         a[13] |= bit
-        self.check(self.lib.adi_explicit_sweep0(*a, h._p(t_out), h._p(xlo), h._p(xhi), h._p(w), w.numel(), h._stream()))
+        self.check(self.lib.adi_explicit_sweep0(*a, h._p(t_out), h._p(xlo), h._p(xhi), self._fc(pack), h._p(w), w.numel(),
+                                                h._stream()))
         self._learn(key, w)
 
     # deferred form of the sharded-axis sweep (include/adi_hip.h, ABI v12): every line solved with zero boundary values by
@@ -333,8 +342,8 @@ class HipEngine:
         key, bit = self._promise('sweep', 1, variant, Li, flags, pack)
         a = list(self._args(1, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf))
         a[12] |= bit
-        self.check(self.lib.adi_sweep_corrected(*a[1:], h._p(t_out), h._p(ulo), h._p(uhi), h._p(w_corr), h._p(w), w.numel(),
-                                                h._stream()))
+        self.check(self.lib.adi_sweep_corrected(*a[1:], h._p(t_out), h._p(ulo), h._p(uhi), h._p(w_corr), self._fc(pack),
+                                                h._p(w), w.numel(), h._stream()))
         self._learn(key, w)
 
     def condense0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, cond, r0_out=None):
@@ -343,7 +352,7 @@ class HipEngine:
         w = self._workspace(L)
         self.check(self.lib.adi_explicit_condense0(*self._fused_args(variant, L, T_ext, i0, j0, flags, pack, dx, dt,
                                                                      kappa, theta, Tinf),
-                                                   h._p(cond), h._p(r0_out), h._p(w), w.numel(), h._stream()))
+                                                   h._p(cond), h._p(r0_out), self._fc(pack), h._p(w), w.numel(), h._stream()))
 
     # pass A folded into the marching explicit kernel: dot products of R0 with fixed weights (uniform lines), the rest
     # condensed from the stored R0 (include/adi_hip.h, adi_axis0_dots_*)

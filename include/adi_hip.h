@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 13
+#define ADI_ABI_VERSION 14
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -157,13 +157,25 @@ int adi_explicit_rhs_planes(const double *d_T, const uint8_t *d_flags, int nx, i
  * d_work/work_bytes (adi_sweep_workspace_bytes): c'/d' scratch for lines longer than the in-register limit,
  * otherwise the unit queue that lets a sparse sweep run as a FAST kernel (solid interior) followed by the
  * GENERAL kernel on the queued surface units; with NULL/0 the GENERAL kernel processes everything.
+
+ * h_face_consts (ABI v14, optional, HOST pointer to 4 doubles; NULL: read the arrays): packs built from per-face SCALARS
+ * (adi_face_constants) -- (c-, c+, q-, q+) = h_f dx^2 / (rho cp dx^3) and q_f dx^2 / (rho cp dx^3) of the minus / plus face
+ * of the sweep axis.  The coefficient of a cell exposed along the axis is then (0 + [no minus neighbour] c-) + [no plus
+ * neighbour] c+ -- the accumulation order of the reference (:93-99), hence the value stored in the array bit for bit -- and
+ * follows from the flags byte alone: the kernels do not load coeff / qflux at all (on a curved solid those loads can only be
+ * issued after the flags have arrived).  Honoured only together with `sparse` (stale / hand-built packs are read).
  */
 int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
               const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux,
               int nx, int ny, int nz, long plane_stride, int sparse,
               double theta, double gam, double dt, double Tinf,
-              double *d_out, const double *d_xlo, const double *d_xhi,
+              double *d_out, const double *d_xlo, const double *d_xhi, const double *h_face_consts,
               void *d_work, size_t work_bytes, void *stream);
+/* (c-, c+, q-, q+) per axis for adi_sweep & co.: h_consts[12] = [axis][4], h_valid[3] = 1 where both faces of the axis carry
+ * scalars or nothing (ADI_FACE_SCALAR / ADI_FACE_NONE) for h AND q -- only then may h_consts + 4*axis be passed on.
+ * Host arithmetic, the very expressions of adi_build_coeffs. */
+int adi_face_constants(double dx, double rho, double cp, const int *h_mode, const double *h_scalar, const int *q_mode,
+                       const double *q_scalar, double *h_consts, int *h_valid);
 int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, long plane_stride, size_t *bytes);
 
 /*
@@ -175,7 +187,7 @@ int adi_sweep_workspace_bytes(int axis, int nx, int ny, int nz, long plane_strid
 int adi_sweep_condense(int axis, int variant, const double *d_in, const uint8_t *d_flags,
                        const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
                        const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse,
-                       double theta, double gam, double dt, double Tinf, double *d_cond,
+                       double theta, double gam, double dt, double Tinf, double *d_cond, const double *h_face_consts,
                        void *d_work, size_t work_bytes, void *stream);
 /*
  * Explicit stage folded into the axis-0 sweep (ABI v7): lap1D_x/y/z + R0 (adi3d_numba_coeff.py:240-288, :292-298)
@@ -196,13 +208,14 @@ int adi_explicit_sweep0(int variant, const double *d_T, long valid_lo, long vali
                         const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
                         const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse,
                         double dx, double dt, double kappa, double theta, double Tinf,
-                        double *d_out, const double *d_xlo, const double *d_xhi,
+                        double *d_out, const double *d_xlo, const double *d_xhi, const double *h_face_consts,
                         void *d_work, size_t work_bytes, void *stream);
 int adi_explicit_condense0(int variant, const double *d_T, long valid_lo, long valid_hi, const uint8_t *d_flags,
                            const double *d_coeff, const uint8_t *d_dir_mask, const double *d_dir_val,
                            const double *d_qflux, int nx, int ny, int nz, long plane_stride, int sparse,
                            double dx, double dt, double kappa, double theta, double Tinf,
-                           double *d_cond, double *d_R0_out, void *d_work, size_t work_bytes, void *stream);
+                           double *d_cond, double *d_R0_out, const double *h_face_consts,
+                           void *d_work, size_t work_bytes, void *stream);
 /*
  * Pass A folded into the explicit stage (ABI v7): for a line whose rows are uniform along axis 0 (solid interior; at
  * most one end row differs) the six pass-A numbers follow from two dot products of R0 with fixed weights -- the first
@@ -271,7 +284,7 @@ int adi_sweep_corrected(int variant, const double *d_in, const uint8_t *d_flags,
                         int nx, int ny, int nz, long plane_stride, int sparse,
                         double theta, double gam, double dt, double Tinf,
                         double *d_out, const double *d_ulo, const double *d_uhi, const double *d_w,
-                        void *d_work, size_t work_bytes, void *stream);
+                        const double *h_face_consts, void *d_work, size_t work_bytes, void *stream);
 
 /*
  * adi_step_numba_coeff / adi_step_gpu_coeff: adi3d_numba_coeff.py:290-302, adi3d_gpu_coeff.py:213-230.
@@ -282,7 +295,8 @@ int adi_step(const double *d_T_in, double *d_T_out, double *d_tmp_a, double *d_t
              const uint8_t *d_flags, const double *const *d_coeff, const uint8_t *d_dir_mask,
              const double *d_dir_val, const double *const *d_qflux, int variant, int sparse,
              int nx, int ny, int nz, long plane_stride, double dx, double rho, double cp, double k,
-             double dt, double theta, double Tinf, void *d_work, size_t work_bytes, void *stream);
+             double dt, double theta, double Tinf, const double *h_face_consts /* [3][4] or NULL, see adi_sweep */,
+             void *d_work, size_t work_bytes, void *stream);
 /* The same step, reporting in h_queued[axis] (three HOST words, valid once the stream is synchronised) how many units the
  * FAST kernel of each sweep handed to the GENERAL kernel.  That number depends on the flags, the Dirichlet mask, the
  * variant, `sparse` and the shape only, so three zeros license bit 2 of `sparse` (the no-fallback promise, see adi_sweep) on
@@ -291,7 +305,8 @@ int adi_step_queued(const double *d_T_in, double *d_T_out, double *d_tmp_a, doub
              const uint8_t *d_flags, const double *const *d_coeff, const uint8_t *d_dir_mask,
              const double *d_dir_val, const double *const *d_qflux, int variant, int sparse,
              int nx, int ny, int nz, long plane_stride, double dx, double rho, double cp, double k,
-             double dt, double theta, double Tinf, void *d_work, size_t work_bytes, void *stream, unsigned *h_queued);
+             double dt, double theta, double Tinf, const double *h_face_consts,
+             void *d_work, size_t work_bytes, void *stream, unsigned *h_queued);
 
 /*
  * The callers either side of the path.  Masks here are DENSE uint8 (nx, ny, nz), C order.

@@ -20,7 +20,7 @@ def test_header_symbols_exported_and_bound():
         assert n in _lib.SIGNATURES, 'ctypes binding missing for %s' % n
     for n in _lib.SIGNATURES:
         assert n in names, '%s bound but not declared in include/adi_hip.h' % n
-    assert _lib.lib.adi_abi_version() == 13
+    assert _lib.lib.adi_abi_version() == 14
 
 
 def test_argument_errors_without_gpu():
@@ -32,7 +32,7 @@ def test_argument_errors_without_gpu():
         _lib.check(_lib.lib.adi_exposed_mask(ctypes.c_void_p(8), 2, 2, 2, 0, 9, ctypes.c_void_p(8), None))
     with pytest.raises(ValueError):
         _lib.check(_lib.lib.adi_sweep(5, 0, None, None, None, None, None, None, 1, 1, 1, 0, 0, 0.5, 1.0, 1.0, 0.0,
-                                      None, None, None, None, 0, None))
+                                      None, None, None, None, None, 0, None))
     with pytest.raises(ValueError, match='unknown zbc.kind_bot'):
         h = ctypes.c_void_p()
         _lib.check(_lib.lib.adi_cyl_plan_create(4, 4, 4, 0, 1e-3, 0.1, 1e-3, 1.0, 1.0, 1.0, 0.1, 0.0, 0.0, 7, 0,

@@ -550,6 +550,28 @@ def _thin_walls(shape, axis, rng, walls=((1, 0.12), (2, 0.2), (4, 0.29), (6, 0.3
     return m
 
 
+@pytest.mark.parametrize('cfl', [1e-13, 1e-9, 1e-3, 0.3, 3e4])
+def test_curved_solid_over_the_range_of_time_steps(hip, cfl):
+    """the surface-segment lanes of the FAST kernels condense their run with a growing three-term recurrence instead of a
+    reciprocal chain (adi_core.hpp, mixed_condense): growth (2 + 1/(theta*gamma))^15 per segment, so sweeps with
+    theta*gamma < 1e-12 go to the GENERAL kernels; every regime against the oracle on an ellipsoid with a void"""
+    from oracle import adi_oracle as orc
+    shape = (256, 48, 256)
+    g = np.meshgrid(*[(np.arange(n) + 0.5) / n - 0.5 for n in shape], indexing='ij')
+    mask = ((g[0] / 0.47) ** 2 + (g[1] / 0.49) ** 2 + (g[2] / 0.48) ** 2 <= 1.0) & \
+        ~((g[0] / 0.12) ** 2 + (g[1] / 0.2) ** 2 + (g[2] / 0.1) ** 2 <= 1.0)
+    rng = np.random.default_rng(41)
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask, T0=rng.uniform(20.0, 1500.0, shape),
+             dir_mask=None, dir_value=None, neumann={'z-': 2e5}, robin_h=350.0, Tinf=20.0, theta=0.5,
+             dt=cfl * dx * dx / alpha, nsteps=2, births=None)
+    got = run_cart_case(hip, c)['T_final']
+    want = run_cart_case(orc, c)['T_final']
+    assert np.array_equal(got[~mask], want[~mask])
+    assert rel_linf(got, want) <= TOL, (cfl, rel_linf(got, want))
+
+
 @pytest.mark.parametrize('shape,axis', [((256, 64, 48), 2), ((256, 48, 64), 1), ((64, 256, 48), 0), ((48, 64, 256), 0),
                                         ((96, 96, 96), 2), ((512, 32, 32), 1)])
 @pytest.mark.parametrize('bc', ['lean', 'neumann'])
