@@ -37,3 +37,41 @@ def test_argument_errors_without_gpu():
         h = ctypes.c_void_p()
         _lib.check(_lib.lib.adi_cyl_plan_create(4, 4, 4, 0, 1e-3, 0.1, 1e-3, 1.0, 1.0, 1.0, 0.1, 0.0, 0.0, 7, 0,
                                                 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, ctypes.byref(h)))
+
+
+def test_face_constants_are_the_pack_values_bit_for_bit():
+    """adi_face_constants (host arithmetic, no GPU): the per-face scalars a sweep is given instead of loading coefficients
+    must be the numbers precompute_coeff_packs_unified stores -- checked against the pinned oracle's packs on a mask whose
+    cells are exposed on the minus face, the plus face, both, or neither, for every axis"""
+    import ctypes
+    import numpy as np
+    from adi_thermal_fields_amd import _lib
+    from oracle import adi_oracle as orc
+    rng = np.random.default_rng(5)
+    shape = (7, 6, 8)
+    mask = rng.random(shape) > 0.35
+    dx, rho, cp = 1.3e-3, 7800.0, 490.0
+    h = {'x-': 410.0, 'x+': 37.5, 'y-': 0.0, 'y+': 999.0, 'z-': 12.25, 'z+': 500.0}
+    q = {'x+': 2e5, 'z-': -3.5e4}
+    grid = orc.Grid3D(*shape, dx, mask)
+    packs = orc.precompute_coeff_packs_unified(grid, orc.Material(rho, cp, 54.0), neumann=q, robin_h=h)
+    faces = ('x-', 'x+', 'y-', 'y+', 'z-', 'z+')
+    I6, D6 = ctypes.c_int * 6, ctypes.c_double * 6
+    hm, hs = I6(*[1] * 6), D6(*[h[f] for f in faces])
+    qm, qs = I6(*[1 if f in q else 0 for f in faces]), D6(*[q.get(f, 0.0) for f in faces])
+    consts, valid = (ctypes.c_double * 12)(), (ctypes.c_int * 3)()
+    _lib.check(_lib.lib.adi_face_constants(dx, rho, cp, hm, hs, qm, qs, consts, valid))
+    assert list(valid) == [1, 1, 1]
+    m = np.pad(mask, 1)
+    for a in range(3):
+        sl = lambda d: tuple(slice(1 + (d if i == a else 0), 1 + (d if i == a else 0) + shape[i]) for i in range(3))
+        lo, hi = m[sl(-1)], m[sl(+1)]                      # the minus / plus neighbour along axis a is in the mask
+        cm, cpl, qmn, qpl = consts[4 * a:4 * a + 4]
+        want_c = np.where(mask, (0.0 + np.where(~lo, cm, 0.0)) + np.where(~hi, cpl, 0.0), 0.0)
+        want_q = np.where(mask, (0.0 + np.where(~lo, qmn, 0.0)) + np.where(~hi, qpl, 0.0), 0.0)
+        assert np.array_equal(want_c, packs[a].coeff), a
+        assert np.array_equal(want_q, packs[a].qflux), a
+    # a per-voxel field on one face of an axis: no constants for that axis
+    hm2 = I6(1, 2, 1, 1, 1, 1)
+    _lib.check(_lib.lib.adi_face_constants(dx, rho, cp, hm2, hs, qm, qs, consts, valid))
+    assert list(valid) == [0, 1, 1]
