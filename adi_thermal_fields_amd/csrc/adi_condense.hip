@@ -446,6 +446,62 @@ __global__ __launch_bounds__(256) void k_interface_deferred(const double *__rest
     uhi[l] = hi;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K5d: the deferred form WITHOUT decay (thin slabs, strong scaling).  x = x0 + xlo * psi_lo + xhi * psi_hi still holds;
+// what changes is that (1) the interface system couples all ranks -- the all-gather + k_interface of the `exact` form, fed
+// with gF = x0_first, gL = x0_last (planes of x0) and the matrix entries below -- and (2) on the first / last rank the
+// homogeneous solutions feel the global end row, whose diagonal differs from the uniform one by delta = dt * coeff - tg
+// (a line start / end with its Robin coefficient).  Sherman-Morrison on the uniform matrix U (p0 = w0 / tg = (U^-1)_00,
+// pn = wn / tg = (U^-1)_0,n-1), kappa = delta / (1 + delta p0):
+//     first rank (row 0 modified):   psi_hi[i] = w[n-1-i] - kappa pn w[i]      (no psi_lo: nothing below)
+//     last rank (row n-1 modified):  psi_lo[i] = w[i] - kappa pn w[n-1-i]      (no psi_hi)
+// so the correction keeps the form  c_lo * w[i] + c_hi * w[n-1-i]  that adi_sweep_corrected applies, with per-line c_lo / c_hi.
+// k_deferred_exact_setup: once per plan -- matrix entries (aF, cF, aL, cL) into rows 1, 2, 4, 5 of the cond block (rows 0 / 3
+// receive the planes of x0 every step) and kappa * pn per line and end (0 where the end row is an ordinary interior row).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_deferred_exact_setup(const uint8_t *__restrict__ flags_first,
+                                                              const uint8_t *__restrict__ flags_last,
+                                                              const double *__restrict__ coeff_first,
+                                                              const double *__restrict__ coeff_last, double tg, double dt,
+                                                              double w0, double wn, long nlines, double *__restrict__ cond,
+                                                              double *__restrict__ kap)
+{
+    const long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlines) return;
+    const bool has_lo = (flags_first[l] & 2u) != 0, has_hi = (flags_last[l] & 4u) != 0;   // the line continues below / above
+    const double p0 = w0 / tg, pn = wn / tg;
+    double aF = 0.0, cF = 0.0, aL = 0.0, cL = 0.0, klo = 0.0, khi = 0.0;
+    if (has_lo && has_hi) {                       // a middle rank: psi_lo = w, psi_hi = reversed w
+        aF = -w0; cF = -wn; aL = -wn; cL = -w0;
+    } else if (has_hi) {                          // first rank: row 0 is the global line start
+        const double delta = dt * coeff_first[l] - tg;
+        const double kappa = delta / (1.0 + delta * p0);
+        klo = kappa * pn;                         // psi_hi = rev(w) - klo * w
+        cF = -(wn - klo * w0);
+        cL = -(w0 - klo * wn);
+    } else if (has_lo) {                          // last rank: row n-1 is the global line end
+        const double delta = dt * coeff_last[l] - tg;
+        const double kappa = delta / (1.0 + delta * p0);
+        khi = kappa * pn;                         // psi_lo = w - khi * rev(w)
+        aF = -(w0 - khi * wn);
+        aL = -(wn - khi * w0);
+    }
+    cond[nlines + l] = aF; cond[2 * nlines + l] = cF; cond[4 * nlines + l] = aL; cond[5 * nlines + l] = cL;
+    kap[l] = klo; kap[nlines + l] = khi;
+}
+
+// per step, after the interface solve: the coefficients of w[i] and w[n-1-i] in the correction of every line
+__global__ __launch_bounds__(256) void k_deferred_exact_coef(const double *__restrict__ xlo, const double *__restrict__ xhi,
+                                                             const double *__restrict__ kap, long nlines,
+                                                             double *__restrict__ clo, double *__restrict__ chi)
+{
+    const long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlines) return;
+    const double lo = xlo[l], hi = xhi[l];        // (0 where there is no neighbour: k_interface)
+    clo[l] = __builtin_fma(-kap[l], hi, lo);            // first rank: xlo = 0, c_lo = -klo * xhi
+    chi[l] = __builtin_fma(-kap[nlines + l], lo, hi);   // last rank:  xhi = 0, c_hi = -khi * xlo
+}
+
 }  // namespace adi
 
 using namespace adi;
@@ -512,6 +568,28 @@ int adi_interface_deferred(const double *d_first, const double *d_last, const do
     const double idet = 1.0 / (1.0 - omega * omega);
     hipLaunchKernelGGL(k_interface_deferred, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, as_stream(stream),
                        d_first, d_last, d_prev_last, d_next_first, omega, idet, nlines, d_ulo, d_uhi);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+int adi_deferred_exact_setup(const uint8_t *d_flags_first, const uint8_t *d_flags_last, const double *d_coeff_first,
+                             const double *d_coeff_last, double theta, double gam, double dt, double w0, double wn,
+                             long nlines, double *d_cond, double *d_kap, void *stream)
+{
+    ADI_REQUIRE(d_flags_first && d_flags_last && d_coeff_first && d_coeff_last && d_cond && d_kap && nlines > 0,
+                "adi_deferred_exact_setup: bad argument");
+    ADI_REQUIRE(theta * gam > 0.0 && w0 > 0.0, "adi_deferred_exact_setup: needs theta*gam > 0");
+    hipLaunchKernelGGL(k_deferred_exact_setup, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       d_flags_first, d_flags_last, d_coeff_first, d_coeff_last, theta * gam, dt, w0, wn, nlines, d_cond, d_kap);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+int adi_deferred_exact_coef(const double *d_xlo, const double *d_xhi, const double *d_kap, long nlines, double *d_clo,
+                            double *d_chi, void *stream)
+{
+    ADI_REQUIRE(d_xlo && d_xhi && d_kap && d_clo && d_chi && nlines > 0, "adi_deferred_exact_coef: bad argument");
+    hipLaunchKernelGGL(k_deferred_exact_coef, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, as_stream(stream), d_xlo,
+                       d_xhi, d_kap, nlines, d_clo, d_chi);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }

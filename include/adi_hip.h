@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 14
+#define ADI_ABI_VERSION 15
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -279,6 +279,20 @@ int adi_axis0_deferred_setup(int n, double theta, double gam, double tol, double
 int adi_interface_deferred(const double *d_first, const double *d_last, const double *d_prev_last,
                            const double *d_next_first, double omega, long nlines, double *d_ulo, double *d_uhi,
                            void *stream);
+/* The deferred form WITHOUT decay (ABI v15: thin slabs / strong scaling, e.g. 512^3 over 8 GPUs = 64 planes at cfl 200).
+ * x = x0 + c_lo w[i] + c_hi w[n-1-i] still holds (adi_axis0_deferred_setup with tol = 0: no weight is cut); the interface
+ * system now couples all ranks: all-gather the [6][nlines] block whose rows 0 / 3 are planes 0 / nx-1 of x0 and whose rows
+ * 1, 2, 4, 5 (aF, cF, aL, cL: constants of the plan) adi_deferred_exact_setup writes once, then adi_interface_solve as in the
+ * two-pass `exact` form.  On the first / last rank the homogeneous solutions feel the global end row (its Robin
+ * coefficient, read from planes 0 / nx-1 of the axis-0 coefficient array); Sherman-Morrison keeps the correction in the
+ * two-vector form with per-line coefficients: adi_deferred_exact_coef turns the interface values (d_xlo, d_xhi) into
+ * (d_clo, d_chi) for adi_sweep_corrected.  d_flags_first / _last, d_coeff_first / _last: planes 0 and nx-1 (dense ny*nz);
+ * w0 = w[0], wn = w[nx-1]; d_kap: 2*nlines doubles of scratch that belong to the plan. */
+int adi_deferred_exact_setup(const uint8_t *d_flags_first, const uint8_t *d_flags_last, const double *d_coeff_first,
+                             const double *d_coeff_last, double theta, double gam, double dt, double w0, double wn,
+                             long nlines, double *d_cond, double *d_kap, void *stream);
+int adi_deferred_exact_coef(const double *d_xlo, const double *d_xhi, const double *d_kap, long nlines, double *d_clo,
+                            double *d_chi, void *stream);
 int adi_sweep_corrected(int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
                         const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux,
                         int nx, int ny, int nz, long plane_stride, int sparse,
