@@ -84,6 +84,7 @@ SIGNATURES = {
     'adi_interface_deferred': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_long, c_void_p, c_void_p, c_void_p]),
     'adi_deferred_exact_setup': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_double,
                                          c_long, c_void_p, c_void_p, c_void_p]),
+    'adi_interface_solve_uniform': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]),
     'adi_deferred_exact_coef': (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     'adi_sweep_corrected': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double,

@@ -87,7 +87,9 @@ inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok,
             const int lpf = next_pow2(n / mf);
             int lg = lf;                                  // GENERAL lines: lf, or lf/2 when the workgroup gets too big
             while (lg * P.Lpg > maxg && lg > 8) lg >>= 1;
-            if (lf * lpf <= 512 && lf * lpf >= 256 && lg * P.Lpg <= maxg && lg * P.Lpg >= 64) {
+            // (workgroups of 128 threads are allowed since round 3: 64-row lines -- the slabs of a 512^3 grid cut over 8 GPUs --
+            // had no FAST kernel at all, 16 lines x 8 segments being below the old minimum of 256: fused kernel 0.144 -> 0.095 ms)
+            if (lf * lpf <= 512 && lf * lpf >= 128 && lg * P.Lpg <= maxg && lg * P.Lpg >= 64) {
                 P.Mf = mf; P.Lpf = lpf; P.lines_f = lf; lines = lg; P.ratio = lf / lg;
             }
         }

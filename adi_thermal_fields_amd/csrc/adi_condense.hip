@@ -286,6 +286,50 @@ __global__ __launch_bounds__(256) void k_interface(const double *__restrict__ co
     xhi[id] = S.gF - S.aF * l;
 }
 
+// The same solve for the deferred form without decay: only the right-hand sides (gF, gL) = (plane 0, plane n-1 of x0) are
+// gathered every step, g_all [nranks][2][nlines]; the matrix entries are constants of the plan -- per line on the first and
+// the last rank (their global end rows: mat_all [nranks][4][nlines] = aF, cF, aL, cL, gathered once), the same two numbers
+// (-w0, -wn) for every line of a middle rank (scal_all [nranks][2]).  A third of the per-step payload and of this kernel's reads.
+__global__ __launch_bounds__(256) void k_interface_uniform(const double *__restrict__ g_all, const double *__restrict__ mat_all,
+                                                           const double *__restrict__ scal_all, int nranks, int rank,
+                                                           long nlines, double *__restrict__ xlo, double *__restrict__ xhi)
+{
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nlines) return;
+    auto ld = [&](int r) {
+        const double *g = g_all + (long)r * 2 * nlines + id;
+        Cond k;
+        k.gF = g[0]; k.gL = g[nlines];
+        if (r == 0 || r == nranks - 1) {
+            const double *m = mat_all + (long)r * 4 * nlines + id;
+            k.aF = m[0]; k.cF = m[nlines]; k.aL = m[2 * nlines]; k.cL = m[3 * nlines];
+        } else {
+            const double w0 = scal_all[2 * r], wn = scal_all[2 * r + 1];
+            k.aF = -w0; k.cF = -wn; k.aL = -wn; k.cL = -w0;
+        }
+        return k;
+    };
+    const Cond C = ld(rank);
+    Cond P = {0, 0, 0, 0, 0, 0}, S = {0, 0, 0, 0, 0, 0};
+    if (rank > 0) {
+        P = ld(0);
+        for (int r = 1; r < rank; ++r) P = merge_cond(P, ld(r));
+    }
+    if (rank < nranks - 1) {
+        S = ld(nranks - 1);
+        for (int r = nranks - 2; r > rank; --r) S = merge_cond(ld(r), S);
+    }
+    const double m00 = 1.0 - C.aF * P.cL, m01 = -C.cF * S.aF;      // (as in k_interface)
+    const double m10 = -C.aL * P.cL, m11 = 1.0 - C.cL * S.aF;
+    const double r0 = C.gF - C.aF * P.gL - C.cF * S.gF;
+    const double r1 = C.gL - C.aL * P.gL - C.cL * S.gF;
+    const double idet = 1.0 / (m00 * m11 - m01 * m10);
+    const double f = (r0 * m11 - m01 * r1) * idet;
+    const double l = (m00 * r1 - m10 * r0) * idet;
+    xlo[id] = P.gL - P.cL * f;
+    xhi[id] = S.gF - S.aF * l;
+}
+
 // Neighbour-only form of the interface system, valid when the far-side couplings of the boundary windows
 // (aL of the window that ends a slab, cF of the window that starts one) have decayed below rounding:
 //   x_last(r)    = gL  - cL  * x_first(r+1)        (window = last rows of slab r)
@@ -456,14 +500,14 @@ __global__ __launch_bounds__(256) void k_interface_deferred(const double *__rest
 //     first rank (row 0 modified):   psi_hi[i] = w[n-1-i] - kappa pn w[i]      (no psi_lo: nothing below)
 //     last rank (row n-1 modified):  psi_lo[i] = w[i] - kappa pn w[n-1-i]      (no psi_hi)
 // so the correction keeps the form  c_lo * w[i] + c_hi * w[n-1-i]  that adi_sweep_corrected applies, with per-line c_lo / c_hi.
-// k_deferred_exact_setup: once per plan -- matrix entries (aF, cF, aL, cL) into rows 1, 2, 4, 5 of the cond block (rows 0 / 3
-// receive the planes of x0 every step) and kappa * pn per line and end (0 where the end row is an ordinary interior row).
+// k_deferred_exact_setup: once per plan -- matrix entries mat [4][nlines] = (aF, cF, aL, cL) of this rank and kappa * pn per
+// line and end (0 where the end row is an ordinary interior row).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_deferred_exact_setup(const uint8_t *__restrict__ flags_first,
                                                               const uint8_t *__restrict__ flags_last,
                                                               const double *__restrict__ coeff_first,
                                                               const double *__restrict__ coeff_last, double tg, double dt,
-                                                              double w0, double wn, long nlines, double *__restrict__ cond,
+                                                              double w0, double wn, long nlines, double *__restrict__ mat,
                                                               double *__restrict__ kap)
 {
     const long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -486,7 +530,7 @@ __global__ __launch_bounds__(256) void k_deferred_exact_setup(const uint8_t *__r
         aF = -(w0 - khi * wn);
         aL = -(wn - khi * w0);
     }
-    cond[nlines + l] = aF; cond[2 * nlines + l] = cF; cond[4 * nlines + l] = aL; cond[5 * nlines + l] = cL;
+    mat[l] = aF; mat[nlines + l] = cF; mat[2 * nlines + l] = aL; mat[3 * nlines + l] = cL;
     kap[l] = klo; kap[nlines + l] = khi;
 }
 
@@ -573,13 +617,24 @@ int adi_interface_deferred(const double *d_first, const double *d_last, const do
 }
 int adi_deferred_exact_setup(const uint8_t *d_flags_first, const uint8_t *d_flags_last, const double *d_coeff_first,
                              const double *d_coeff_last, double theta, double gam, double dt, double w0, double wn,
-                             long nlines, double *d_cond, double *d_kap, void *stream)
+                             long nlines, double *d_mat, double *d_kap, void *stream)
 {
-    ADI_REQUIRE(d_flags_first && d_flags_last && d_coeff_first && d_coeff_last && d_cond && d_kap && nlines > 0,
+    ADI_REQUIRE(d_flags_first && d_flags_last && d_coeff_first && d_coeff_last && d_mat && d_kap && nlines > 0,
                 "adi_deferred_exact_setup: bad argument");
     ADI_REQUIRE(theta * gam > 0.0 && w0 > 0.0, "adi_deferred_exact_setup: needs theta*gam > 0");
     hipLaunchKernelGGL(k_deferred_exact_setup, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       d_flags_first, d_flags_last, d_coeff_first, d_coeff_last, theta * gam, dt, w0, wn, nlines, d_cond, d_kap);
+                       d_flags_first, d_flags_last, d_coeff_first, d_coeff_last, theta * gam, dt, w0, wn, nlines, d_mat, d_kap);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+int adi_interface_solve_uniform(const double *d_g_all, const double *d_mat_all, const double *d_scal_all, int nranks, int rank,
+                                long nlines, double *d_xlo, double *d_xhi, void *stream)
+{
+    ADI_REQUIRE(d_g_all && d_mat_all && d_scal_all && d_xlo && d_xhi && nranks >= 2 && rank >= 0 && rank < nranks && nlines > 0,
+                "adi_interface_solve_uniform: bad argument");
+    hipLaunchKernelGGL(k_interface_uniform, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, as_stream(stream), d_g_all,
+                       d_mat_all, d_scal_all, nranks, rank, nlines, d_xlo, d_xhi);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }

@@ -330,6 +330,30 @@ class HipEngine:
                                                      h._stream()))
         return dict(w=w, omega=om.value, reach=reach.value)
 
+    def deferred_exact_setup(self, Li, flags_int, pack, theta, gam, dt, dfr, mat, scal):
+        """once per plan: this rank's matrix entries mat [4][nlines] = (aF, cF, aL, cL), its (w[0], w[n-1]) in `scal`, and the
+        per-line Sherman-Morrison factors of a global end row (first / last rank) -> opaque handle for deferred_exact_coef"""
+        h = self.hip
+        nl = Li.ny * Li.nz
+        kap = self.vec(2 * nl)
+        w = dfr['w']
+        w0, wn = float(w[0].item()), float(w[Li.nx - 1].item())
+        scal[0] = w0; scal[1] = wn
+        self.check(self.lib.adi_deferred_exact_setup(h._p(flags_int[0]), h._p(flags_int[Li.nx - 1]), h._p(pack[0][0]),
+                                                     h._p(pack[0][Li.nx - 1]), theta, gam, dt, w0, wn, nl, h._p(mat), h._p(kap),
+                                                     h._stream()))
+        return dict(kap=kap)
+
+    def interface_uniform(self, g_all, mat_all, scal_all, world, rank, nlines, xlo, xhi):
+        h = self.hip
+        self.check(self.lib.adi_interface_solve_uniform(h._p(g_all), h._p(mat_all), h._p(scal_all), world, rank, nlines,
+                                                        h._p(xlo), h._p(xhi), h._stream()))
+
+    def deferred_exact_coef(self, dx_, xlo, xhi, nlines, clo, chi):
+        h = self.hip
+        self.check(self.lib.adi_deferred_exact_coef(h._p(xlo), h._p(xhi), h._p(dx_['kap']), nlines, h._p(clo), h._p(chi),
+                                                    h._stream()))
+
     def interface_deferred(self, first, last, prev_last, next_first, omega, nlines, ulo, uhi):
         h = self.hip
         self.check(self.lib.adi_interface_deferred(h._p(first), h._p(last), h._p(prev_last), h._p(next_first), omega,
@@ -442,6 +466,7 @@ class SlabStepper:
         self._keep_r0 = True                       # False: pass B re-evaluates the explicit stage instead of reading R0
         self._allow_dots = True                    # False: pass A as its own kernel (reads the slab a second time)
         self._allow_deferred = True                # False: never the deferred form (zero-boundary solve + correction on load)
+        self._allow_deferred_exact = True          # False: thin slabs (no decay) keep the two-pass all-gather form
         self._send_g_only = True                   # False: every step exchanges the matrix parts of the interface too
         self._comm_stream, self._use_streams = None, False
         self._halo_ready, self._halo_event = None, None
@@ -507,7 +532,7 @@ class SlabStepper:
 
     @property
     def stage_names(self):
-        if self._a0 is not None and self._a0['mode'] == 'deferred':
+        if self._a0 is not None and self._a0['mode'].startswith('deferred'):
             a1 = 'interface+sweep_axis1_corrected'
             if self._a0['fused']:
                 return ['halo+explicit+sweep_axis0_zero_boundary', a1, 'sweep_axis2_contig']
@@ -520,7 +545,7 @@ class SlabStepper:
     def pass_a_form(self):
         """how pass A of the sharded-axis sweep runs under the current plan (bench.py reports it)"""
         p = self._a0 or {}
-        if p.get('mode') == 'deferred':
+        if str(p.get('mode')).startswith('deferred'):
             return 'none (zero-boundary solve; planes 0 and n-1 of its result are the pass-A right-hand sides)'
         return 'dots_in_explicit' if p.get('dots') else ('fused' if p.get('fused') else 'separate')
 
@@ -529,7 +554,7 @@ class SlabStepper:
         """algorithmic HBM bytes per local cell of the stages (pass A re-reads the inputs of the rows it covers)"""
         bpc = self._bpc
         frac = 0.0
-        if self._a0 is not None and self._a0['mode'] == 'deferred':
+        if self._a0 is not None and self._a0['mode'].startswith('deferred'):
             # one pass per sweep; the two interface planes the axis-1 sweep re-reads are 2 * ny * nz values per slab
             return [bpc[0], bpc[1], bpc[2]] if self._a0['fused'] else [self._explicit_bpc, bpc[0], bpc[1], bpc[2]]
         if self.world > 1:
@@ -622,7 +647,8 @@ class SlabStepper:
         'slab' (the whole slab is its own window).  Collective: every rank calls it at the same step."""
         prm = self.params
         key = (float(prm.dt), float(prm.theta), self._mask_version, self._force_exact, self._no_overlap,
-               self._allow_fused, self._allow_window, self._keep_r0, self._allow_dots, self._allow_deferred)
+               self._allow_fused, self._allow_window, self._keep_r0, self._allow_dots, self._allow_deferred,
+               self._allow_deferred_exact)
         if self._a0_key == key:
             return self._a0
         E, v = self.engine, self.variant
@@ -650,25 +676,43 @@ class SlabStepper:
             return Lw, worst, bool(worst <= self.DECAY_TOL)          # NaN compares false -> not decayed
         # Deferred form first (its eligibility costs one pass over the flags and a host-side solve): every sharded-axis
         # line of every slab uniform -- solid, no Dirichlet cell -- and the homogeneous solution decayed across every slab.
-        dfr = None
-        if self._allow_deferred and not self._force_exact and hasattr(E, 'deferred_setup') and self.nxl >= 2:
-            dset = E.deferred_setup(self.nxl, prm.theta, gam, self.DECAY_TOL)
-            if dset['reach'] < self.nxl and E.lines_all_uniform(self.Lint, fl, pk[1]):
-                dfr = dset
-        dflag = E.vec(2)
+        # Where the weights have NOT decayed across a slab (thin slabs: strong scaling) the same algebra holds with the
+        # interface system of all ranks (all-gather) and per-line end corrections on the first / last rank: 'deferred_exact'.
+        dfr, uniform = None, False
+        if self._allow_deferred and hasattr(E, 'deferred_setup') and self.nxl >= 2 and prm.theta * gam > 0.0:
+            uniform = bool(E.lines_all_uniform(self.Lint, fl, pk[1]))
+            if uniform:
+                dfr = E.deferred_setup(self.nxl, prm.theta, gam, self.DECAY_TOL)
+        dflag = E.vec(3)
         dflag[0] = 1.0 if dfr is not None else 0.0
         dflag[1] = 1.0 if (self._allow_fused and hasattr(E, 'sweep0_fused')
                            and E.fused_supported(self.nxl, self.ny, self.nz, self.Lint.sx, False)) else 0.0
-        alld = E.vec(2 * self.world)
+        dflag[2] = 1.0 if (dfr is not None and dfr['reach'] < self.nxl) else 0.0
+        alld = E.vec(3 * self.world)
         self.comm.all_gather(alld, dflag)
-        alld = alld.view(self.world, 2)
+        alld = alld.view(self.world, 3)
         if float(alld[:, 0].min()) >= 1.0:
             nl_ = self.nlines
-            plan = dict(mode='deferred', K=dfr['reach'], dfr=dfr, fused=bool(float(alld[:, 1].min()) >= 1.0), dots=False,
-                        keep_r0=False, chunks=[], ulo=E.vec(nl_), uhi=E.vec(nl_), prev_last=E.vec(nl_), next_first=E.vec(nl_))
-            self._a0_key, self._a0 = key, plan
-            self.axis0_mode = 'deferred'
-            return plan
+            all_decayed = float(alld[:, 2].min()) >= 1.0 and not self._force_exact
+            plan = dict(mode='deferred' if all_decayed else 'deferred_exact', K=dfr['reach'], dfr=dfr,
+                        fused=bool(float(alld[:, 1].min()) >= 1.0), dots=False, keep_r0=False, chunks=[],
+                        ulo=E.vec(nl_), uhi=E.vec(nl_))
+            if all_decayed:
+                plan.update(prev_last=E.vec(nl_), next_first=E.vec(nl_))
+            elif hasattr(E, 'deferred_exact_setup') and self._allow_deferred_exact:
+                plan['dfr'] = E.deferred_setup(self.nxl, prm.theta, gam, 0.0)          # no weight is cut
+                mat, scal = E.vec(4 * nl_), E.vec(2)
+                plan.update(g=E.vec(2 * nl_), g_all=E.vec(2 * nl_ * self.world), mat_all=E.vec(4 * nl_ * self.world),
+                            scal_all=E.vec(2 * self.world), xlo=E.vec(nl_), xhi=E.vec(nl_))
+                plan['dx'] = E.deferred_exact_setup(self.Lint, fl, pk, prm.theta, gam, prm.dt, plan['dfr'], mat, scal)
+                self.comm.all_gather(plan['mat_all'], mat)          # the matrix entries travel once per plan
+                self.comm.all_gather(plan['scal_all'], scal)
+            else:
+                plan = None
+            if plan is not None:
+                self._a0_key, self._a0 = key, plan
+                self.axis0_mode = plan['mode']
+                return plan
         K = self._window_guess(gam)
         cand = {}
         if not self._force_exact:
@@ -860,8 +904,8 @@ class SlabStepper:
         src = t.clone()
         a = self.step(src)
         a = (a.t if hasattr(a, 't') and not isinstance(a, torch.Tensor) else a).clone()
-        keep = (self._no_overlap, self._force_exact)
-        self._no_overlap, self._force_exact = True, True
+        keep = (self._no_overlap, self._force_exact, self._allow_deferred)
+        self._no_overlap, self._force_exact, self._allow_deferred = True, True, False     # the two-pass all-gather form
         b = self.step(src)
         b = b.t if hasattr(b, 't') and not isinstance(b, torch.Tensor) else b
         den = float(b.abs().max())
@@ -869,8 +913,9 @@ class SlabStepper:
         ok = torch.tensor([1.0 if err <= 1e-12 else 0.0], dtype=torch.float64, device=self.engine.device)
         allok = self.engine.vec(self.world)
         self.comm.all_gather(allok, ok)                 # the ranks must not end up in different configurations
+        self._allow_deferred = keep[2]
         if float(allok.min()) >= 1.0:
-            self._no_overlap, self._force_exact = keep
+            self._no_overlap, self._force_exact = keep[:2]
         return err, not self._no_overlap
 
     def step(self, T, events=None, prefetch_halo=False):
@@ -920,7 +965,7 @@ class SlabStepper:
         self._halo_ready = None
 
         # 2. explicit stage, 3. axis-0 sweep
-        if plan is not None and plan['mode'] == 'deferred':
+        if plan is not None and plan['mode'].startswith('deferred'):
             # every line of the slab solved with ZERO boundary values by the single-domain kernels; the first and last plane
             # of that result go to the neighbours, the 2 x 2 interface systems give the two boundary values of every line, and
             # the axis-1 sweep adds  ulo * w[i] + uhi * w[n-1-i]  to what it loads (step 4)
@@ -941,20 +986,39 @@ class SlabStepper:
                 mark()
                 E.sweep(0, v, Li, Ai, fl, self.packs_int[0], prm.theta, gam, prm.dt, self.Tinf, Bi)
             mark()
-            if streams:
-                ev0 = torch.cuda.Event(); ev0.record(main)
-                with torch.cuda.stream(self._comm_stream):
-                    self._comm_stream.wait_event(ev0)
+            if plan['mode'] == 'deferred_exact':
+                # no decay: all-gather of (plane 0, plane n-1) of x0 -- the right-hand sides of the interface system, whose matrix
+                # is the plan's -- the interface solve over all ranks, then the per-line coefficients of w[i] and w[n-1-i]
+                g2 = plan['g'].view(2, self.ny, self.nz)
+                g2[0].copy_(Bi[0]); g2[1].copy_(Bi[nl - 1])
+                if streams:
+                    ev0 = torch.cuda.Event(); ev0.record(main)
+                    with torch.cuda.stream(self._comm_stream):
+                        self._comm_stream.wait_event(ev0)
+                        self.comm.all_gather(plan['g_all'], plan['g'])
+                        ev1 = torch.cuda.Event(); ev1.record(self._comm_stream)
+                    main.wait_event(ev1)
+                else:
+                    self.comm.all_gather(plan['g_all'], plan['g'])
+                E.interface_uniform(plan['g_all'], plan['mat_all'], plan['scal_all'], self.world, self.rank, self.nlines,
+                                    plan['xlo'], plan['xhi'])
+                E.deferred_exact_coef(plan['dx'], plan['xlo'], plan['xhi'], self.nlines, plan['ulo'], plan['uhi'])
+            else:
+                if streams:
+                    ev0 = torch.cuda.Event(); ev0.record(main)
+                    with torch.cuda.stream(self._comm_stream):
+                        self._comm_stream.wait_event(ev0)
+                        self.comm.exchange_planes(Bi[0], Bi[nl - 1], plan['prev_last'].view(self.ny, self.nz),
+                                                  plan['next_first'].view(self.ny, self.nz))
+                        ev1 = torch.cuda.Event(); ev1.record(self._comm_stream)
+                    main.wait_event(ev1)
+                else:
                     self.comm.exchange_planes(Bi[0], Bi[nl - 1], plan['prev_last'].view(self.ny, self.nz),
                                               plan['next_first'].view(self.ny, self.nz))
-                    ev1 = torch.cuda.Event(); ev1.record(self._comm_stream)
-                main.wait_event(ev1)
-            else:
-                self.comm.exchange_planes(Bi[0], Bi[nl - 1], plan['prev_last'].view(self.ny, self.nz),
-                                          plan['next_first'].view(self.ny, self.nz))
-            first, last = self.rank == 0, self.rank == self.world - 1
-            E.interface_deferred(Bi[0], Bi[nl - 1], None if first else plan['prev_last'], None if last else plan['next_first'],
-                                 plan['dfr']['omega'], self.nlines, plan['ulo'], plan['uhi'])
+                first, last = self.rank == 0, self.rank == self.world - 1
+                E.interface_deferred(Bi[0], Bi[nl - 1], None if first else plan['prev_last'],
+                                     None if last else plan['next_first'], plan['dfr']['omega'], self.nlines, plan['ulo'],
+                                     plan['uhi'])
         elif fused:
             # R0 never reaches HBM: both passes of the axis-0 sweep evaluate it from the state (halo planes included,
             # so they must have landed; in an nsub loop they were sent while the previous step's last sweep ran)
@@ -1018,10 +1082,11 @@ class SlabStepper:
             ev_x = self._axis0_pipeline(plan, Ai, Bi)
             self._axis0_finish(plan, Ai, Bi, ev_x)
         # 4. local sweeps
-        if plan is not None and plan['mode'] == 'deferred':
+        if plan is not None and plan['mode'].startswith('deferred'):
+            ex_ = plan['mode'] == 'deferred_exact'        # (there the end ranks carry a Sherman-Morrison term on both vectors)
             E.sweep_corrected(v, Li, Bi, fl, self.packs_int[1], prm.theta, gam, prm.dt, self.Tinf, Ai,
-                              None if self.rank == 0 else plan['ulo'], None if self.rank == self.world - 1 else plan['uhi'],
-                              plan['dfr']['w'])
+                              None if (self.rank == 0 and not ex_) else plan['ulo'],
+                              None if (self.rank == self.world - 1 and not ex_) else plan['uhi'], plan['dfr']['w'])
         else:
             mark()
             E.sweep(1, v, Li, Bi, fl, self.packs_int[1], prm.theta, gam, prm.dt, self.Tinf, Ai)

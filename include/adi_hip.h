@@ -281,16 +281,21 @@ int adi_interface_deferred(const double *d_first, const double *d_last, const do
                            void *stream);
 /* The deferred form WITHOUT decay (ABI v15: thin slabs / strong scaling, e.g. 512^3 over 8 GPUs = 64 planes at cfl 200).
  * x = x0 + c_lo w[i] + c_hi w[n-1-i] still holds (adi_axis0_deferred_setup with tol = 0: no weight is cut); the interface
- * system now couples all ranks: all-gather the [6][nlines] block whose rows 0 / 3 are planes 0 / nx-1 of x0 and whose rows
- * 1, 2, 4, 5 (aF, cF, aL, cL: constants of the plan) adi_deferred_exact_setup writes once, then adi_interface_solve as in the
- * two-pass `exact` form.  On the first / last rank the homogeneous solutions feel the global end row (its Robin
- * coefficient, read from planes 0 / nx-1 of the axis-0 coefficient array); Sherman-Morrison keeps the correction in the
- * two-vector form with per-line coefficients: adi_deferred_exact_coef turns the interface values (d_xlo, d_xhi) into
- * (d_clo, d_chi) for adi_sweep_corrected.  d_flags_first / _last, d_coeff_first / _last: planes 0 and nx-1 (dense ny*nz);
- * w0 = w[0], wn = w[nx-1]; d_kap: 2*nlines doubles of scratch that belong to the plan. */
+ * system now couples all ranks, as in the two-pass `exact` form, but only its right-hand sides change from step to step:
+ *   per step   all-gather [2][nlines] = (plane 0, plane nx-1 of x0) -> d_g_all [nranks][2][nlines]   (a third of the payload
+ *              of the six-number block), adi_interface_solve_uniform -> (d_xlo, d_xhi), adi_deferred_exact_coef -> the
+ *              per-line coefficients (d_clo, d_chi) of w[i] and w[nx-1-i] for adi_sweep_corrected;
+ *   per plan   adi_deferred_exact_setup: d_mat [4][nlines] = (aF, cF, aL, cL) of this rank and d_kap [2][nlines], the
+ *              Sherman-Morrison factors of a global end row (first / last rank: the line start / end with its Robin
+ *              coefficient, read from planes 0 / nx-1 of the axis-0 coefficient array); all-gather d_mat ->
+ *              d_mat_all [nranks][4][nlines] (read for ranks 0 and nranks-1 only: a middle rank's entries are the two numbers
+ *              (w[0], w[nx-1]) of ITS slab, d_scal_all [nranks][2], gathered likewise -- slabs may differ in thickness).
+ * d_flags_first / _last, d_coeff_first / _last: planes 0 and nx-1 (dense ny*nz). */
 int adi_deferred_exact_setup(const uint8_t *d_flags_first, const uint8_t *d_flags_last, const double *d_coeff_first,
                              const double *d_coeff_last, double theta, double gam, double dt, double w0, double wn,
-                             long nlines, double *d_cond, double *d_kap, void *stream);
+                             long nlines, double *d_mat, double *d_kap, void *stream);
+int adi_interface_solve_uniform(const double *d_g_all, const double *d_mat_all, const double *d_scal_all, int nranks, int rank,
+                                long nlines, double *d_xlo, double *d_xhi, void *stream);
 int adi_deferred_exact_coef(const double *d_xlo, const double *d_xhi, const double *d_kap, long nlines, double *d_clo,
                             double *d_chi, void *stream);
 int adi_sweep_corrected(int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,

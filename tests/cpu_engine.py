@@ -176,6 +176,49 @@ class CpuEngine:
             g = np.stack([last.numpy().reshape(-1), next_first.numpy().reshape(-1)])
             hi[:] = np.linalg.solve(M, g)[1]
 
+    # the deferred form without decay: homogeneous solutions of every line by a dense solve with the line's actual end rows,
+    # and the two coefficients by least squares on (w, reversed w) -- independent of the product's Sherman-Morrison formulas
+    def interface_uniform(self, g_all, mat_all, scal_all, world, rank, nlines, xlo, xhi):
+        G = g_all.view(world, 2, nlines).numpy(); M = mat_all.view(world, 4, nlines).numpy()
+        S = scal_all.view(world, 2).numpy()
+        C = np.zeros((world, 6, nlines))
+        for r in range(world):
+            C[r, 0] = G[r, 0]; C[r, 3] = G[r, 1]
+            if r in (0, world - 1):
+                C[r, 1], C[r, 2], C[r, 4], C[r, 5] = M[r]
+            else:
+                C[r, 1] = -S[r, 0]; C[r, 2] = -S[r, 1]; C[r, 4] = -S[r, 1]; C[r, 5] = -S[r, 0]
+        self.interface(torch.from_numpy(C.reshape(-1)), world, rank, nlines, xlo, xhi)
+
+    def deferred_exact_setup(self, Li, flags_int, pack, theta, gam, dt, dfr, mat, scal):
+        tg = theta * gam
+        n, nl = Li.nx, Li.ny * Li.nz
+        zero = torch.zeros(Li.shape, dtype=torch.float64)
+        a, b, c, _ = _line_systems(0, zero, flags_int, pack, theta, gam, dt, 0.0)
+        mv = lambda v: v.reshape(n, nl).T
+        a, b, c = mv(a), mv(b), mv(c)
+        psi_lo, psi_hi = np.zeros((nl, n)), np.zeros((nl, n))
+        C = np.zeros((6, nl))
+        w = dfr['w'].numpy()
+        scal[0] = float(w[0]); scal[1] = float(w[n - 1])
+        for l in range(nl):
+            Ainv = np.linalg.inv(_dense(a[l], b[l], c[l]))
+            if a[l, 0] != 0.0:
+                psi_lo[l] = tg * Ainv[:, 0]
+            if c[l, -1] != 0.0:
+                psi_hi[l] = tg * Ainv[:, -1]
+            C[1, l] = -psi_lo[l, 0]; C[2, l] = -psi_hi[l, 0]; C[4, l] = -psi_lo[l, -1]; C[5, l] = -psi_hi[l, -1]
+        mat.view(4, nl).numpy()[:] = C[[1, 2, 4, 5]]
+        return dict(psi_lo=psi_lo, psi_hi=psi_hi, w=dfr['w'].numpy().copy())
+
+    def deferred_exact_coef(self, dx_, xlo, xhi, nlines, clo, chi):
+        w = dx_['w']
+        B = np.stack([w, w[::-1]], axis=1)                         # (n, 2)
+        t = xlo.numpy()[:, None] * dx_['psi_lo'] + xhi.numpy()[:, None] * dx_['psi_hi']      # (nlines, n)
+        sol, res, _, _ = np.linalg.lstsq(B, t.T, rcond=None)
+        assert np.abs(B @ sol - t.T).max() <= 1e-9 * max(1.0, np.abs(t).max())           # the two-vector form is exact
+        clo.numpy()[:] = sol[0]; chi.numpy()[:] = sol[1]
+
     def sweep_corrected(self, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, ulo, uhi, w_corr):
         w = w_corr.numpy()
         x = t_in.numpy().copy()

@@ -92,6 +92,7 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q, opts=None):
         st._keep_r0 = bool(opts.get('keep_r0', True))
         st._allow_dots = bool(opts.get('allow_dots', True))
         st._allow_deferred = bool(opts.get('allow_deferred', True))
+        st._allow_deferred_exact = bool(opts.get('allow_deferred_exact', True))
         T = torch.from_numpy(np.ascontiguousarray(c['T0'][i0:i1]))
         for s in range(nsteps):
             T = st.step(T, prefetch_halo=bool(opts.get('prefetch', False)) and s + 1 < nsteps)
@@ -203,7 +204,11 @@ def test_world_4_and_8_every_interface_form(world, name, sizes, opts, mode):
     (4, 'solid:256:2.0', [64] * 4, dict(prefetch=True), 'deferred'),                           # weights reach ~60 rows
     (8, 'solid:192:0.1', [24] * 8, dict(prefetch=True), 'deferred'),
     (4, 'solid:128:0.1', [32] * 4, dict(prefetch=True, allow_deferred=False), 'slab'),         # the two-pass form on the same case
-    (4, 'solid:64:200', [16] * 4, dict(prefetch=True), 'exact'),                               # nothing decays: not eligible
+    (4, 'solid:64:200', [16] * 4, dict(prefetch=True), 'deferred_exact'),                      # nothing decays: all-gather form
+    (3, 'solid:42:200', [16, 14, 12], dict(prefetch=True, allow_fused=False), 'deferred_exact'),   # uneven thin slabs
+    (8, 'solid:64:200', [8] * 8, dict(prefetch=True), 'deferred_exact'),                       # the strong-scaling shape
+    (2, 'solid:24:50', [12, 12], dict(prefetch=True), 'deferred_exact'),                       # both ranks carry an end row
+    (4, 'solid:64:200', [16] * 4, dict(prefetch=True, allow_deferred_exact=False), 'exact'),   # the two-pass form on the same case
     (3, 'decay:96', [32, 32, 32], dict(prefetch=True), 'slab'),                                # voids: lines not uniform
 ])
 def test_deferred_form_matches_single_domain(world, name, sizes, opts, mode):

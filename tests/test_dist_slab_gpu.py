@@ -39,6 +39,7 @@ def _run_slabs(c, world, sizes, nsteps, opts=None, modes=None):
             st._allow_dots = bool(o.get('allow_dots', True))
             st._keep_r0 = bool(o.get('keep_r0', True))
             st._allow_deferred = bool(o.get('allow_deferred', True))
+            st._allow_deferred_exact = bool(o.get('allow_deferred_exact', True))
             if 'dots_max' in o:
                 st.DOTS_MAX_NONUNIFORM = o['dots_max']
             T = hip.to_device(np.ascontiguousarray(c['T0'][i0:i1]))
@@ -138,7 +139,13 @@ def test_slabs_interface_forms_agree(cfl, opts, mode):
     ((192, 24, 40), [64] * 3, 1.0, dict(prefetch=True), 'deferred'),                       # nz not a multiple of 16: GENERAL kernels
     ((128, 70, 16), [64, 64], 1.0, dict(prefetch=True), 'deferred'),                       # ragged axis-1 lines
     ((256, 16, 64), [64] * 4, 3.0, dict(prefetch=True, allow_deferred=False), 'slab'),     # the two-pass form on the same grid
-    ((256, 16, 64), [64] * 4, 300.0, dict(prefetch=True), 'exact'),                        # nothing decays across 64 rows
+    ((256, 16, 64), [64] * 4, 300.0, dict(prefetch=True), 'deferred_exact'),               # nothing decays across 64 rows
+    ((256, 16, 64), [64] * 4, 300.0, dict(prefetch=True, allow_fused=False), 'deferred_exact'),
+    ((192, 24, 40), [64] * 3, 2000.0, dict(prefetch=True), 'deferred_exact'),              # GENERAL axis-1 kernels, stiff
+    ((128, 16, 64), [64, 64], 200.0, dict(prefetch=True), 'deferred_exact'),               # two ranks, both with a global end row
+    ((512, 16, 32), [64] * 8, 200.0, dict(prefetch=True), 'deferred_exact'),               # the strong-scaling shape: 8 x 64 planes
+    ((254, 16, 64), [64, 62, 64, 64], 300.0, dict(prefetch=True), 'deferred_exact'),       # uneven thin slabs
+    ((256, 16, 64), [64] * 4, 300.0, dict(prefetch=True, allow_deferred_exact=False), 'exact'),   # the two-pass all-gather form
 ])
 def test_slabs_deferred_form(shape, sizes, cfl, opts, mode):
     """all-solid slabs: the sharded-axis sweep as the single-domain (fused) kernel with zero boundary values + one plane to
