@@ -204,6 +204,12 @@ class HipEngine:
         self.mask_epoch = 0        # bumped by SlabStepper.set_mask: the flags / packs are rebuilt in place
         self._nofb = {}            # no-fallback promise per sweep configuration (bit 2 of `sparse`, include/adi_hip.h)
         self._fconsts = {}         # coefficient storage -> per-face scalars of the pack built on it (h_face_consts)
+        self._stream_ptr = None    # launch stream of the step in progress (SlabStepper.step pins it: one lookup per step)
+        self._wb = {}              # workspace bytes per box shape
+
+    def _sp(self):
+        """the hipStream_t every kernel of this engine is launched on: torch's current stream, looked up once per step"""
+        return self._stream_ptr if self._stream_ptr is not None else self.hip._stream()
 
     def layout(self, nx, ny, nz, sx=None):
         return self.hip.Layout(nx, ny, nz, sx)
@@ -214,7 +220,7 @@ class HipEngine:
     def build_flags(self, L, mask_ext):
         flags = L.empty(torch.uint8, zero=True)
         self.check(self.lib.adi_build_nbr_flags(self.hip._p(mask_ext), L.nx, L.ny, L.nz, L.sx, self.hip._p(flags),
-                                                self.hip._stream()))
+                                                self._sp()))
         return flags
 
     def _fc(self, pack):
@@ -233,11 +239,33 @@ class HipEngine:
         self._fconsts = {p.d_coeff.untyped_storage().data_ptr(): p.face_consts for p in packs if p.face_consts is not None}
         return packs
 
+    # in-place updates after a layer birth (planes [k0, k1) of axis 2): what Grid3D.set_mask_device / BirthPacks.update do
+    # for one domain, here on the extended arrays of a slab
+    def build_flags_planes(self, L, mask_ext, flags_ext, k0, k1):
+        self.check(self.lib.adi_build_nbr_flags_planes(self.hip._p(mask_ext), L.nx, L.ny, L.nz, L.sx, self.hip._p(flags_ext),
+                                                       int(k0), int(k1), self._sp()))
+
+    def build_packs_planes(self, L, mask_ext, packs_ext, dx, mat, specs, k0, k1):
+        h = self.hip
+        hm, hs, qm, qs = specs
+        none6 = h.ptr_array([None] * 6)
+        self.check(self.lib.adi_build_coeffs_planes(h._p(mask_ext), L.nx, L.ny, L.nz, L.sx, float(dx), mat.rho, mat.cp,
+                                                    hm, hs, none6, qm, qs, none6,
+                                                    h.ptr_array([p.d_coeff.data_ptr() for p in packs_ext]),
+                                                    h.ptr_array([p.d_qflux.data_ptr() for p in packs_ext]),
+                                                    int(k0), int(k1), self._sp()))
+
+    def birth_planes(self, Li, T_int, act_int, full_int, k0, k1, Ts, count):
+        """adi_birth_planes on the interior of a slab (pointers one plane into the extended arrays)"""
+        h = self.hip
+        self.check(self.lib.adi_birth_planes(h._p(T_int), h._p(act_int), h._p(full_int), Li.nx, Li.ny, Li.nz, Li.sx,
+                                             int(k0), int(k1), float(Ts), h._p(count), self._sp()))
+
     def explicit(self, L, T_ext, flags_ext, dx, dt, kappa, theta, out_ext, i_begin=0, i_end=None):
         h = self.hip
         i_end = L.nx if i_end is None else i_end
         self.check(self.lib.adi_explicit_rhs_planes(h._p(T_ext), h._p(flags_ext), L.nx, L.ny, L.nz, L.sx, dx, dt, kappa,
-                                                    theta, h._p(out_ext), i_begin, i_end, h._stream()))
+                                                    theta, h._p(out_ext), i_begin, i_end, self._sp()))
 
     def _args(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf):
         h = self.hip
@@ -246,11 +274,15 @@ class HipEngine:
 
     def _workspace(self, Li):
         """unit queue of the FAST/GENERAL kernel pair (sized for the largest box seen)"""
-        need = 0
-        for ax in range(3):
-            b = ctypes.c_size_t(0)
-            self.check(self.lib.adi_sweep_workspace_bytes(ax, Li.nx, Li.ny, Li.nz, Li.sx, ctypes.byref(b)))
-            need = max(need, b.value)
+        key = (Li.nx, Li.ny, Li.nz, Li.sx)
+        need = self._wb.get(key)
+        if need is None:
+            need = 0
+            for ax in range(3):
+                b = ctypes.c_size_t(0)
+                self.check(self.lib.adi_sweep_workspace_bytes(ax, Li.nx, Li.ny, Li.nz, Li.sx, ctypes.byref(b)))
+                need = max(need, b.value)
+            self._wb[key] = need
         if getattr(self, '_work', None) is None or self._work.numel() < need:
             self._work = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._work
@@ -277,14 +309,14 @@ class HipEngine:
         key, bit = self._promise('sweep', axis, variant, Li, flags, pack)
         a = list(self._args(axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf))
         a[12] |= bit
-        self.check(self.lib.adi_sweep(*a, h._p(t_out), h._p(xlo), h._p(xhi), self._fc(pack), h._p(w), w.numel(), h._stream()))
+        self.check(self.lib.adi_sweep(*a, h._p(t_out), h._p(xlo), h._p(xhi), self._fc(pack), h._p(w), w.numel(), self._sp()))
         self._learn(key, w)
 
     def condense(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, cond):
         h = self.hip
         w = self._workspace(Li)
         self.check(self.lib.adi_sweep_condense(*self._args(axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf),
-                                               h._p(cond), self._fc(pack), h._p(w), w.numel(), h._stream()))
+                                               h._p(cond), self._fc(pack), h._p(w), w.numel(), self._sp()))
 
     # explicit stage folded into the axis-0 sweep / condensation (ABI v7).  The box (L.nx, L.ny, L.nz) starts at plane
     # i0, row j0 of the extended state T_ext; neighbours outside the box are read from T_ext itself.
@@ -305,7 +337,7 @@ class HipEngine:
         a = list(self._fused_args(variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf))
         a[13] |= bit
         self.check(self.lib.adi_explicit_sweep0(*a, h._p(t_out), h._p(xlo), h._p(xhi), self._fc(pack), h._p(w), w.numel(),
-                                                h._stream()))
+                                                self._sp()))
         self._learn(key, w)
 
     # deferred form of the sharded-axis sweep (include/adi_hip.h, ABI v12): every line solved with zero boundary values by
@@ -318,7 +350,7 @@ class HipEngine:
         cls = torch.empty(nl, dtype=torch.uint8, device=self.device)
         lst = torch.empty(nl + 1, dtype=torch.int32, device=self.device)
         self.check(self.lib.adi_axis0_classify(h._p(flags_int), h._p(dmask_int), Li.nx, Li.ny, Li.nz, Li.sx, h._p(cls),
-                                               h._p(lst), h._stream()))
+                                               h._p(lst), self._sp()))
         return int(lst[0].item()) == 0
 
     def deferred_setup(self, n, theta, gam, tol):
@@ -327,7 +359,7 @@ class HipEngine:
         w = self.vec(n)
         om, reach = ctypes.c_double(0.0), ctypes.c_int(0)
         self.check(self.lib.adi_axis0_deferred_setup(n, theta, gam, tol, h._p(w), ctypes.byref(om), ctypes.byref(reach),
-                                                     h._stream()))
+                                                     self._sp()))
         return dict(w=w, omega=om.value, reach=reach.value)
 
     def deferred_exact_setup(self, Li, flags_int, pack, theta, gam, dt, dfr, mat, scal):
@@ -341,23 +373,23 @@ class HipEngine:
         scal[0] = w0; scal[1] = wn
         self.check(self.lib.adi_deferred_exact_setup(h._p(flags_int[0]), h._p(flags_int[Li.nx - 1]), h._p(pack[0][0]),
                                                      h._p(pack[0][Li.nx - 1]), theta, gam, dt, w0, wn, nl, h._p(mat), h._p(kap),
-                                                     h._stream()))
+                                                     self._sp()))
         return dict(kap=kap)
 
     def interface_uniform(self, g_all, mat_all, scal_all, world, rank, nlines, xlo, xhi):
         h = self.hip
         self.check(self.lib.adi_interface_solve_uniform(h._p(g_all), h._p(mat_all), h._p(scal_all), world, rank, nlines,
-                                                        h._p(xlo), h._p(xhi), h._stream()))
+                                                        h._p(xlo), h._p(xhi), self._sp()))
 
     def deferred_exact_coef(self, dx_, xlo, xhi, nlines, clo, chi):
         h = self.hip
         self.check(self.lib.adi_deferred_exact_coef(h._p(xlo), h._p(xhi), h._p(dx_['kap']), nlines, h._p(clo), h._p(chi),
-                                                    h._stream()))
+                                                    self._sp()))
 
     def interface_deferred(self, first, last, prev_last, next_first, omega, nlines, ulo, uhi):
         h = self.hip
         self.check(self.lib.adi_interface_deferred(h._p(first), h._p(last), h._p(prev_last), h._p(next_first), omega,
-                                                   nlines, h._p(ulo), h._p(uhi), h._stream()))
+                                                   nlines, h._p(ulo), h._p(uhi), self._sp()))
 
     def sweep_corrected(self, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, ulo, uhi, w_corr):
         """axis-1 sweep of t_in + w[i] * ulo + w[n-1-i] * uhi"""
@@ -367,7 +399,7 @@ class HipEngine:
         a = list(self._args(1, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf))
         a[12] |= bit
         self.check(self.lib.adi_sweep_corrected(*a[1:], h._p(t_out), h._p(ulo), h._p(uhi), h._p(w_corr), self._fc(pack),
-                                                h._p(w), w.numel(), h._stream()))
+                                                h._p(w), w.numel(), self._sp()))
         self._learn(key, w)
 
     def condense0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, cond, r0_out=None):
@@ -376,7 +408,7 @@ class HipEngine:
         w = self._workspace(L)
         self.check(self.lib.adi_explicit_condense0(*self._fused_args(variant, L, T_ext, i0, j0, flags, pack, dx, dt,
                                                                      kappa, theta, Tinf),
-                                                   h._p(cond), h._p(r0_out), self._fc(pack), h._p(w), w.numel(), h._stream()))
+                                                   h._p(cond), h._p(r0_out), self._fc(pack), h._p(w), w.numel(), self._sp()))
 
     # pass A folded into the marching explicit kernel: dot products of R0 with fixed weights (uniform lines), the rest
     # condensed from the stored R0 (include/adi_hip.h, adi_axis0_dots_*)
@@ -391,9 +423,9 @@ class HipEngine:
         dd = dict(weights=self.vec(Li.nx), part=self.vec(pb.value // 8),
                   cls=torch.empty(Li.ny * Li.nz, dtype=torch.uint8, device=self.device),
                   list=torch.empty(lb.value // 4, dtype=torch.int32, device=self.device))
-        self.check(self.lib.adi_axis0_dots_setup(Li.nx, theta, gam, h._p(dd['weights']), h._stream()))
+        self.check(self.lib.adi_axis0_dots_setup(Li.nx, theta, gam, h._p(dd['weights']), self._sp()))
         self.check(self.lib.adi_axis0_classify(h._p(flags_int), h._p(dmask_int), Li.nx, Li.ny, Li.nz, Li.sx,
-                                               h._p(dd['cls']), h._p(dd['list']), h._stream()))
+                                               h._p(dd['cls']), h._p(dd['list']), self._sp()))
         return dd
 
     def dots_nonuniform_fraction(self, dd):
@@ -408,25 +440,25 @@ class HipEngine:
         h = self.hip
         self.check(self.lib.adi_explicit_rhs_dots(h._p(T_ext), h._p(flags_ext), L.nx, L.ny, L.nz, L.sx, dx, dt, kappa,
                                                   theta, h._p(out_ext), i_begin, i_end, i_org, n_line,
-                                                  h._p(dd['weights']), h._p(dd['part']), h._stream()))
+                                                  h._p(dd['weights']), h._p(dd['part']), self._sp()))
 
     def dots_finish(self, variant, Li, dd, r0, flags, pack, theta, gam, dt, Tinf, line_begin, line_end, cond):
         h = self.hip
         self.check(self.lib.adi_axis0_dots_finish(variant, h._p(dd['part']), h._p(dd['weights']), h._p(dd['cls']),
                                                   h._p(dd['list']), h._p(r0), h._p(flags), h._p(pack[0]), h._p(pack[1]),
                                                   h._p(pack[2]), h._p(pack[3]), Li.nx, Li.ny, Li.nz, Li.sx, theta, gam, dt,
-                                                  float(Tinf), line_begin, line_end, h._p(cond), h._stream()))
+                                                  float(Tinf), line_begin, line_end, h._p(cond), self._sp()))
 
     def interface(self, cond_all, world, rank, nlines, xlo, xhi):
         h = self.hip
         self.check(self.lib.adi_interface_solve(h._p(cond_all), world, rank, nlines, h._p(xlo), h._p(xhi),
-                                                h._stream()))
+                                                self._sp()))
 
 
     def interface_pair(self, my_lo, my_hi, prev_hi, next_lo, nlines, xlo, xhi):
         h = self.hip
         self.check(self.lib.adi_interface_pair(h._p(my_lo), h._p(my_hi), h._p(prev_hi), h._p(next_lo), nlines,
-                                               h._p(xlo), h._p(xhi), h._stream()))
+                                               h._p(xlo), h._p(xhi), self._sp()))
 
 
 def _interior(t_ext):
@@ -529,6 +561,50 @@ class SlabStepper:
             return tuple(None if t is None else _interior(t) for t in (p.d_coeff, p.d_dir_mask, p.d_dir_val, p.d_qflux))
         self.packs_int = [interior_pack(p) for p in self.packs_ext]
         self.flags_int = _interior(self.flags_ext)
+
+    def _scalar_specs(self):
+        """(h_mode, h_scalar, q_mode, q_scalar) ctypes arrays when every face specification is a scalar or absent, else None"""
+        import ctypes
+        from ._lib import FACES, FACE_NONE, FACE_SCALAR
+        bc = self._bc
+        if bc['dir_mask'] is not None:
+            return None
+        hm, hs, qm, qs = [], [], [], []
+        for f in FACES:
+            rh = bc['robin_h']
+            v = None if rh is None else (rh.get(f, 0.0) if isinstance(rh, dict) else rh)
+            q = None if bc['neumann'] is None else bc['neumann'].get(f)
+            for val, m_, s_ in ((v, hm, hs), (q, qm, qs)):
+                if val is None:
+                    m_.append(FACE_NONE); s_.append(0.0)
+                elif np.isscalar(val):
+                    m_.append(FACE_SCALAR); s_.append(float(val))
+                else:
+                    return None
+        return ((ctypes.c_int * 6)(*hm), (ctypes.c_double * 6)(*hs), (ctypes.c_int * 6)(*qm), (ctypes.c_double * 6)(*qs))
+
+    def device_births_supported(self):
+        """layer births can be applied to the device mask in place (set_mask_device): the product engine, face
+        specifications that are scalars, no Dirichlet cells"""
+        return hasattr(self.engine, 'build_flags_planes') and self._scalar_specs() is not None
+
+    def set_mask_device(self, k_begin, k_end):
+        """`grid.mask = ...; packs = precompute_...` after a layer birth that switched cells on IN the device mask of the slab
+        (the interior planes of self.d_mask_ext, planes [k_begin, k_end) of axis 2; waam.run_layer_birth_slab): the mask halo
+        planes travel, the flags and the six coefficient arrays are rebuilt in place on the planes whose exposure can have
+        changed -- no host copy of the mask, no allocation.  Collective (every rank calls it for every birth)."""
+        E, L = self.engine, self.Lext
+        specs = self._scalar_specs()
+        assert specs is not None and hasattr(E, 'build_flags_planes')
+        self._mask_version += 1
+        E.mask_epoch += 1
+        E._nofb.clear()
+        d_mask = self.d_mask_ext
+        self.comm.exchange_planes(d_mask[1], d_mask[-2], d_mask[0], d_mask[-1])     # (no neighbour: the halo plane stays empty)
+        k0, k1 = max(0, int(k_begin) - 1), min(self.nz, int(k_end) + 1)
+        E.build_flags_planes(L, d_mask, self.flags_ext, k0, k1)
+        E.build_packs_planes(L, d_mask, self.packs_ext, self.dx, self.mat, specs, k0, k1)
+        E.box_hint = 0                 # a part that is still growing is not an all-solid box
 
     @property
     def stage_names(self):
@@ -680,7 +756,10 @@ class SlabStepper:
         # interface system of all ranks (all-gather) and per-line end corrections on the first / last rank: 'deferred_exact'.
         dfr, uniform = None, False
         if self._allow_deferred and hasattr(E, 'deferred_setup') and self.nxl >= 2 and prm.theta * gam > 0.0:
-            uniform = bool(E.lines_all_uniform(self.Lint, fl, pk[1]))
+            # uniform lines need every cell of the slab in the mask: where the engine keeps the collective all-solid hint
+            # (set_mask / set_mask_device) a slab that is not all-solid is not classified at all -- one kernel and one host
+            # synchronisation less in every plan of a layer-birth loop
+            uniform = (getattr(E, 'box_hint', 2) == 2) and bool(E.lines_all_uniform(self.Lint, fl, pk[1]))
             if uniform:
                 dfr = E.deferred_setup(self.nxl, prm.theta, gam, self.DECAY_TOL)
         dflag = E.vec(3)
@@ -772,7 +851,9 @@ class SlabStepper:
         if plan['dots'] or plan['mode'] == 'window':
             ranges = self._chunk_ranges(1)
         elif plan['mode'] == 'exact':
-            ranges = self._chunk_ranges(4)
+            # (small slabs: the kernels of a quarter of the lines take microseconds and the step is bound by the host's
+            # launch path -- 64 x 256 x 320 in the layer-birth loop: 0.94 -> 0.5 ms of host time per step)
+            ranges = self._chunk_ranges(4 if self.nxl * self.ny * self.nz >= (1 << 25) else 1)
         else:
             ranges = self._chunk_ranges(2, self.SLAB_CHUNK_EDGES)
         bufs = []
@@ -924,6 +1005,16 @@ class SlabStepper:
         to the halos: the boundary planes of the result are then computed first and sent to the neighbours while
         the rest of the last sweep runs.  (The other forms start with the planes that need no halo, which hides
         the exchange just as well.)"""
+        E = self.engine
+        if hasattr(E, '_stream_ptr'):
+            E._stream_ptr = E.hip._stream()        # every kernel of this step goes to the stream that is current now
+        try:
+            return self._step(T, events, prefetch_halo)
+        finally:
+            if hasattr(E, '_stream_ptr'):
+                E._stream_ptr = None
+
+    def _step(self, T, events, prefetch_halo):
         E, prm, mat = self.engine, self.params, self.mat
         kappa = self._kappa = mat.k / (mat.rho * mat.cp)         # adi3d_numba_coeff.py:292
         gam = self._gam = kappa * prm.dt / (self.dx * self.dx)

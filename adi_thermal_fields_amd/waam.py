@@ -230,6 +230,19 @@ def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, 
     if on_device:                                   # the slab's field stays in HBM: step() hands back device tensors
         import torch
         T = torch.from_numpy(T).to(st.engine.device)
+    # device loop (as run_layer_birth's): the slab's part of the full mask and its active mask live in HBM; a birth is one
+    # kernel on the layer's planes of the slab + SlabStepper.set_mask_device (mask halo planes, flags and packs rebuilt in
+    # place on those planes).  The host keeps only per-plane bookkeeping: which planes are born, how many cells are active.
+    dev_loop = on_device and st.device_births_supported()
+    if dev_loop:
+        E = st.engine
+        m_ext = np.zeros((i1 - i0 + 2, ny, nz), dtype=np.bool_)
+        m_ext[1:-1] = mask_full[i0:i1]
+        d_full_int = st.Lext.to_layout(m_ext, torch.uint8)[1:-1]
+        count = torch.zeros(1, dtype=torch.int64, device=E.device)
+        plane_cells = np.asarray(mask_full).sum(axis=(0, 1)).astype(np.int64)
+        plane_born = np.zeros(nz, dtype=bool)
+        n_active = 0
     nsteps, next_birth, t_now = 0, 0, 0.0
 
     def advance(seg):
@@ -245,10 +258,20 @@ def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, 
         while next_birth < len(times_birth) and times_birth[next_birth] <= te + 1e-15:
             t_b = times_birth[next_birth]
             seg = max(0.0, t_b - t_now)
-            if seg > 1e-15 and mask_act.any():
+            if seg > 1e-15 and (n_active > 0 if dev_loop else mask_act.any()):
                 advance(seg)
             t_now = t_b
             ks, ke = layers[next_birth]
+            if dev_loop:
+                if not isinstance(T, torch.Tensor) or T.data_ptr() != dist_slab._interior(st._ext_bufs[st._cur]).data_ptr():
+                    T = dist_slab._interior(st._load_state(T))          # the state buffer itself (nothing stepped yet)
+                E.birth_planes(st.Lint, T, dist_slab._interior(st.d_mask_ext), d_full_int, ks, ke + 1, Ts, count)
+                fresh = ~plane_born[ks:ke + 1]
+                n_active += int(plane_cells[ks:ke + 1][fresh].sum())
+                plane_born[ks:ke + 1] = True
+                st.set_mask_device(ks, ke + 1)
+                next_birth += 1
+                continue
             born = np.zeros_like(mask_full, dtype=bool)
             born[:, :, ks:ke + 1] = mask_full[:, :, ks:ke + 1]
             newborn = (born & (~mask_act))[i0:i1]
@@ -263,11 +286,12 @@ def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, 
             st.set_mask(mask_act[i0:i1])
             next_birth += 1
         seg = max(0.0, te - t_now)
-        if seg > 1e-15 and mask_act.any():
+        if seg > 1e-15 and (n_active > 0 if dev_loop else mask_act.any()):
             advance(seg)
         t_now = te
         if on_frame is not None and any(abs(te - to) <= 1e-12 for to in times_out):
-            on_frame(t_now, np.array(st.local_numpy(T)), mask_act[i0:i1].copy())
+            act = dist_slab._interior(st.d_mask_ext).cpu().contiguous().numpy().astype(bool) if dev_loop else mask_act[i0:i1].copy()
+            on_frame(t_now, np.array(st.local_numpy(T)), act)
     return np.array(st.local_numpy(T)), nsteps
 
 
@@ -294,9 +318,15 @@ def run_single_track_slab(comm, i0, i1, plate_mask, track_box, dx, mat, params_c
         import torch
         T = torch.from_numpy(T).to(st.engine.device)
     lx0, lx1 = max(x0, i0) - i0, min(x1, i1) - i0            # the track box inside this slab (empty when lx0 >= lx1)
+    dev_loop = on_device and st.device_births_supported()      # the mask stays in HBM: a column is a slice assignment
     for yi in range(ncol):
-        mask[x0:x1, yi:yi + 1, z0:z1] = True
-        st.set_mask(mask[i0:i1])                               # collective: every rank, whether the column touches it or not
+        if dev_loop:
+            if lx0 < lx1:
+                dist_slab._interior(st.d_mask_ext)[lx0:lx1, yi:yi + 1, z0:z1] = 1
+            st.set_mask_device(z0, z1)                         # collective: halo planes of the mask, flags and packs in place
+        else:
+            mask[x0:x1, yi:yi + 1, z0:z1] = True
+            st.set_mask(mask[i0:i1])                           # collective: every rank, whether the column touches it or not
         if lx0 < lx1:
             if on_device:
                 T[lx0:lx1, yi:yi + 1, z0:z1] = T_track         # in place: the last sub-step sent no halo ahead
