@@ -103,3 +103,36 @@ def test_ctx_learns_the_no_fallback_promise(kind):
             T = np.ascontiguousarray(got)
     finally:
         lib.adi_ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize('shape', [(32, 256, 256), (256, 32, 64), (1040, 16, 16)])
+def test_step_queued_reports_zero_for_sweeps_that_run_no_fast_kernel(shape):
+    """adi_step_queued: a sweep that runs no FAST kernel (lines shorter than 64 rows; lines beyond 1024 rows, where the
+    workspace holds c' / d' doubles) never touches the queue word, so its count must be reported as 0 -- not whatever the
+    workspace held -- or adi_ctx_step would refuse the no-fallback promise for the whole mask / pack epoch on garbage.
+    The workspace is filled with 0xff before the call; an all-solid box queues nothing anywhere."""
+    import torch
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from adi_thermal_fields_amd import _lib
+    lib = _lib.lib
+    nx, ny, nz = shape
+    dx = 1e-3
+    grid = hip.Grid3D(nx, ny, nz, dx, np.ones(shape, bool))
+    mat = hip.Material(7800.0, 490.0, 54.0)
+    packs = hip.precompute_coeff_packs_unified(grid, mat, robin_h=300.0)
+    L = grid.layout
+    T = hip.to_device(np.random.default_rng(3).uniform(20.0, 900.0, shape)).t
+    out, ta, tb = L.empty(), L.empty(), L.empty()
+    _, work, wb = grid.scratch(2)
+    work.fill_(255)
+    q = (ctypes.c_uint * 3)(7, 7, 7)
+    coeff = _lib.ptr_array([p.d_coeff.data_ptr() for p in packs])
+    qflux = _lib.ptr_array([None, None, None])
+    alpha = 54.0 / (7800.0 * 490.0)
+    _lib.check(lib.adi_step_queued(hip._p(T), hip._p(out), hip._p(ta), hip._p(tb), hip._p(grid.d_flags), coeff, None, None, qflux,
+                                   _lib.SWEEP_LEAN, 1, nx, ny, nz, grid.sx, dx, 7800.0, 490.0, 54.0, 50.0 * dx * dx / alpha, 0.5, 20.0,
+                                   None, hip._p(work), wb, hip._stream(), ctypes.cast(q, ctypes.c_void_p)))
+    torch.cuda.synchronize()
+    assert list(q) == [0, 0, 0], list(q)
+    want = hip.adi_step_hip_coeff(hip.DeviceField(T), grid, mat, hip.Params(50.0 * dx * dx / alpha, 0.5), packs, Tinf=20.0).t
+    assert torch.equal(out, want)
