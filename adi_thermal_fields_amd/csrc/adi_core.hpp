@@ -102,6 +102,9 @@ __device__ __forceinline__ void reduced_row(double aS, double bS, double cS, dou
 // (Lp a power of two <= 64, li = lane index inside the line).  Rows outside [0, Lp) are identity.
 __device__ __forceinline__ double pcr_solve(double ra, double rb, double rc, double rd, int li, int Lp)
 {
+#ifdef ADI_EXP_NOPCR      // (timing experiment only: what the interface solve costs; results are wrong)
+    return rd * frcp(rb + ra + rc);
+#endif
     for (int dl = 1; dl < Lp; dl <<= 1) {
         const double inv = frcp(rb);
         const bool hl = (li - dl) >= 0, hh = (li + dl) < Lp;

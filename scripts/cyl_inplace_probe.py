@@ -1,7 +1,7 @@
 """cylindrical 128 x 256 x 512 BE step: the three sweeps ping-ponging between buffers (shipped) against sweeps run IN PLACE
 (every thread of the FAST kernels reads only the rows it later writes), which halves the working set to 134 MB -- inside the
-256 MB Infinity Cache.  Needs a library built with -DADI_CYL_ALLOW_INPLACE (scripts/ab_build.sh cylip ... adi_cyl.hip).
-    ADI_HIP_LIB=scripts/_build/libadi_cylip.so python scripts/cyl_inplace_probe.py"""
+256 MB Infinity Cache.  (adi_cyl_sweep accepts d_out == d_in since ABI v13: this experiment is what decided it.)
+    python scripts/cyl_inplace_probe.py"""
 import os, sys
 import numpy as np
 import torch
