@@ -3,8 +3,9 @@ BASELINE.json's bar).  The fixed cases of test_hip_parity.py were each written f
 under them: line lengths on both sides of every tiling switch (8 / 16 / 32 rows per thread, 8- and 16-line tiles, whole
 and ragged tiles, padded segment counts), dense hand-built packs and sparse device-built packs, every pack variant
 (Dirichlet and / or Neumann present), solid boxes, random holes, curved solids and thin walls, theta in {0.5, 1}.
-One-off soaks with the same generators and the final build of round 2: 3 400 Cartesian and 1 900 cylindrical cases, no failure,
-worst relative L-inf 7.2e-13 / 9.9e-13."""
+One-off soaks with the same generators (scripts/fuzz_soak.py): round 2's final build 3 400 Cartesian and 1 900 cylindrical cases,
+no failure, worst relative L-inf 7.2e-13 / 9.9e-13; round 3 (face constants, reciprocal-free surface runs, 16 rows from 160-row
+lines, 128-thread FAST workgroups, in-place cylindrical sweeps): see profiles/r03_fuzz_soak.txt."""
 import numpy as np
 import pytest
 
@@ -52,7 +53,7 @@ def _case(seed):
         mask[tuple(sl)] = True
     dx = float(rng.choice([2.5e-4, 1e-3]))
     cfl = float(rng.choice([0.7, 20.0, 200.0, 3000.0]))
-    bc = rng.choice(['lean', 'dir', 'neu', 'general', 'array_h'])
+    bc = rng.choice(['lean', 'dir', 'neu', 'general', 'array_h', 'scalar_faces'])
     dir_mask = dir_value = neumann = None
     robin_h = float(rng.uniform(50.0, 900.0))
     if bc in ('dir', 'general'):
@@ -67,6 +68,11 @@ def _case(seed):
         neumann = {str(rng.choice(faces)): float(rng.uniform(-2e5, 2e6)), str(rng.choice(faces)): rng.uniform(0, 1e5, shape)}
     if bc == 'array_h':
         robin_h = {'x-': rng.uniform(0, 800.0, shape), 'y+': 300.0, 'z-': rng.uniform(0, 100.0, shape), 'z+': 40.0}
+    if bc == 'scalar_faces':               # a different scalar on every face, scalar fluxes: the sweeps get face constants with q
+        robin_h = {f: float(rng.uniform(0.0, 900.0)) for f in ['x-', 'x+', 'y-', 'y+', 'z-', 'z+'] if rng.random() < 0.8}
+        neumann = {f: float(rng.uniform(-2e5, 2e6)) for f in ['x-', 'x+', 'y-', 'y+', 'z-', 'z+'] if rng.random() < 0.4}
+        if rng.random() < 0.15:
+            cfl = 1e-13                    # a vanishing time step: GENERAL kernels only (adi_core.hpp, kMixedMinTg)
     return dict(shape=shape, dx=dx, mat=dict(STEEL), mask=mask, T0=rng.uniform(20.0, 1500.0, shape), dir_mask=dir_mask,
                 dir_value=dir_value, neumann=neumann, robin_h=robin_h, Tinf=float(rng.uniform(0.0, 40.0)),
                 theta=float(rng.choice([0.5, 1.0])), dt=cfl * dx * dx / ALPHA, nsteps=2, births=None), (kind, bc, cfl)
