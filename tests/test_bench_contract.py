@@ -1,0 +1,59 @@
+"""GPU: bench.py prints ONE JSON line with the contract's keys (small grid, a few steps): the single-GPU line with `roofline`,
+`cpu_baseline` and `parity_rel_linf`, the rehearsal lines of both scaling modes marked as rehearsals, the cylindrical and the
+curved-solid variants."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+        'dtype', 'data', 'config', 'roofline']
+
+
+def _bench(*args):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]                   # exactly one line on stdout
+    d = json.loads(lines[0])
+    for k in KEYS:
+        assert k in d, k
+    assert d['higher_is_better'] is True and d['dtype'] == 'f64' and d['data'] == 'synthetic' and d['vs_baseline'] is None
+    rf = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in rf, k
+    assert rf['bound'] == 'hbm' and rf['peak'] == 8000.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
+    assert d['value'] > 0 and d['ms_per_step'] > 0 and 'workload' in d['config'] and 'model' not in d['config']
+    return d
+
+
+def test_single_gpu_line_with_cpu_baseline_and_parity():
+    d = _bench('--n', '64', '--cpu-n', '64', '--steps', '4', '--warmup', '2')
+    assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 2 and d['scaling'] == 'weak'
+    cb = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in cb, k
+    assert cb['kind'] == 'port' and cb['cores'] == 1 and d['cpu_baseline_all_cores']['cores'] >= 1
+    assert d['parity_rel_linf'] <= 1e-10 and d['parity']['steps'] == 3
+    assert 'north_star_x_sweep' in d and d['north_star_x_sweep']['target_frac'] == 0.60
+
+
+@pytest.mark.parametrize('scaling,form', [('weak', 'deferred_exact'), ('strong', 'deferred_exact')])   # (256 rows at cfl 200: no decay)
+def test_rehearsal_lines_are_marked(scaling, form):
+    d = _bench('--n', '256', '--steps', '3', '--warmup', '2', '--no-cpu', '--rehearse-world', '4', '--scaling', scaling)
+    assert 'rehearsal' in d and d['n_gpus'] == 1 and d['scaling'] == scaling
+    assert d['comm_overlap']['axis0_interface'] == form and d['comm_overlap']['selfcheck_rel_diff'] <= 1e-12
+    assert d['config']['planes_per_gpu'] == (256 if scaling == 'weak' else 64)
+
+
+def test_curved_solid_and_cylindrical_lines():
+    d = _bench('--n', '128', '--steps', '3', '--warmup', '2', '--no-cpu', '--mask', 'ellipsoid')
+    assert 'ellipsoid' in d['config']['workload']
+    d = _bench('--config', 'cyl', '--steps', '4', '--warmup', '2', '--no-cpu')
+    assert d['metric'].startswith('adi_cyl') and set(d['kernels']) == {'sweep_r', 'sweep_phi', 'sweep_z_contig'}
