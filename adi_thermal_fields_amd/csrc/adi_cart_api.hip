@@ -63,6 +63,7 @@ static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t 
     s.box = (sparse & 2) ? 1 : 0;
     s.nofb = (sparse & 4) ? 1 : 0;
     if (s.tg < kMixedMinTg) s.sparse = 0;   // a vanishing time step: GENERAL kernels only (mixed_condense's recurrence would overflow)
+    s.nt = store_policy_nt(L.nx, L.sx);
     set_face_consts(s, fcs);
     if (c_w != nullptr && (c_lo != nullptr || c_hi != nullptr)) {
         // deferred interface correction (adi_sweep_corrected): the strided kernels of memory axis 1 add it to what they load
@@ -188,6 +189,7 @@ static int condense_entry(int axis, int variant, const double *d_in, const uint8
     s.box = (sparse & 2) ? 1 : 0;
     s.nofb = (sparse & 4) ? 1 : 0;
     if (s.tg < kMixedMinTg) s.sparse = 0;   // (as in sweep_entry)
+    s.nt = store_policy_nt(L.nx, L.sx);
     set_face_consts(s, fcs);
     hipStream_t st = as_stream(stream);
     SweepArgs a;

@@ -43,15 +43,18 @@ __device__ __forceinline__ double2 ld_stream2(const double2 *p)
     return *p;
 #endif
 }
-__device__ __forceinline__ void st_stream2(double2 *p, double2 v)
+// nt: block-uniform, decided by the host per launch (SweepScal::nt): streaming stores for fields that do not fit the 256 MB
+// Infinity Cache, plain stores for fields that do -- the next kernel then reads what this one wrote from the cache
+// (scripts/nt_probe.py: 256^3, 134 MB per field, 0.226 -> 0.204 ms per step with plain stores; 512^3 1.48 against 1.55 with nt)
+__device__ __forceinline__ void st_stream2(double2 *p, double2 v, bool nt = (ADI_STORE_AUX == 2))
 {
-#if ADI_STORE_AUX == 2
-    typedef double d2v __attribute__((ext_vector_type(2)));
-    d2v w; w.x = v.x; w.y = v.y;
-    __builtin_nontemporal_store(w, reinterpret_cast<d2v *>(p));
-#else
-    *p = v;
-#endif
+    if (nt) {
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        d2v w; w.x = v.x; w.y = v.y;
+        __builtin_nontemporal_store(w, reinterpret_cast<d2v *>(p));
+    } else {
+        *p = v;
+    }
 }
 
 struct SweepScal {
@@ -82,7 +85,13 @@ struct SweepScal {
     // second memory latency in every wave that holds a surface row (512^3 ellipsoid: 6 % of the step).
     int fconst = 0;
     double fc[4] = {0.0, 0.0, 0.0, 0.0};
+    int nt = 1;   // streaming output stores (fields beyond the Infinity Cache); 0: plain stores (host: store_policy_nt)
 };
+
+// fields of at most this many bytes are written with plain stores (scripts/nt_probe.py: plain wins up to 134 - 168 MB per
+// field, streaming from 190 MB)
+constexpr size_t kPlainStoreMaxBytes = (size_t)160 << 20;
+inline int store_policy_nt(long nx, long sx) { return ((size_t)nx * (size_t)sx * sizeof(double) > kPlainStoreMaxBytes) ? 1 : 0; }
 
 // Coefficient / flux of an in-mask cell that is exposed along the sweep axis: from the flags (per-face scalars, see
 // SweepScal::fconst) or from the pack array.  has_lo / has_hi: the minus / plus neighbour along the axis is in the mask.
@@ -438,11 +447,13 @@ __device__ __forceinline__ u32x2 as_u32x2(double x)
     v.x = (unsigned)__double2loint(x); v.y = (unsigned)__double2hiint(x);
     return v;
 }
-__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x)
+__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x,
+                                              bool nt = (ADI_STORE_AUX == 2))
 {
     u32x2 v;
     v.x = (unsigned)__double2loint(x); v.y = (unsigned)__double2hiint(x);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, ADI_STORE_AUX);
+    if (nt) __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 2);
+    else __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
 
 // Deferred interface correction (SweepScal::c_*): weights of the plane `to` this tile lies in (block-uniform, scalar
@@ -554,7 +565,8 @@ __device__ __forceinline__ void coal_load(const double *__restrict__ gsrc /* wav
 }
 
 template <int M>
-__device__ __forceinline__ void coal_store(double *__restrict__ gdst, double *strip, int lane, const double (&d)[M])
+__device__ __forceinline__ void coal_store(double *__restrict__ gdst, double *strip, int lane, const double (&d)[M],
+                                           bool nt = (ADI_STORE_AUX == 2))
 {
     constexpr int CH = M + 2;
     constexpr int NJ = (32 * M) / 128 > 0 ? (32 * M) / 128 : 1;
@@ -570,7 +582,7 @@ __device__ __forceinline__ void coal_store(double *__restrict__ gdst, double *st
         for (int j = 0; j < NJ; ++j) {
             const int e = 128 * j + 2 * lane;
             const double2 t = *reinterpret_cast<const double2 *>(strip + (e / M) * CH + (e % M));
-            st_stream2(reinterpret_cast<double2 *>(gdst + h * 32 * M + e), t);
+            st_stream2(reinterpret_cast<double2 *>(gdst + h * 32 * M + e), t, nt);
         }
         wave_lds_fence();
     }

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     if (kind == SEG_UNI || kind == SEG_PAD) back_solve_uniform<M>(U, a0, kappa, d, xL, xS);
     else if (kind >= SEG_TAIL) mixed_lane_back_solve<M>(kind, Lm, U, bmod, a0, d, xL, xS);
     if constexpr (MODE == 2) {
-        coal_store<M>(out + wbase, strip, lane, d);      // (the host takes this mode only when no lane is padding)
+        coal_store<M>(out + wbase, strip, lane, d, s.nt != 0);      // (the host takes this mode only when no lane is padding)
     } else if (pad) {
         // nothing to store
     } else if (VEC) {

@@ -16,6 +16,13 @@
 //             carry the neumann0 / dirichlet / robin closure; the void post-clamp is fused into the store.
 //
 // Algorithmic HBM traffic: 16 B/cell/sweep (+8 with a source, +1 per masked pass).
+// Cache policy of this translation unit: PLAIN loads and stores (the Cartesian kernels stream their outputs with nt stores).
+// The cylindrical sweeps run in place on a field of 134 MB at BASELINE configs[3] -- inside the 256 MB Infinity Cache -- and a
+// streaming store evicts exactly the lines the next sweep is about to read: 0.145 -> 0.133 ms per step in the loop, 0.154 ->
+// 0.143 ms with the reference's step semantics (scripts/cyl_probe.py, nt against plain).
+#define ADI_STORE_AUX 0
+#define ADI_LOAD_NT_CONTIG 0
+#define ADI_CYL_NT 0
 #include <cstdlib>
 #include <math.h>
 #include <string.h>
@@ -314,7 +321,11 @@ __global__ __launch_bounds__(1024) void k_cyl_phi_fast(
 #pragma unroll
     for (int r = 0; r < M; ++r) {
         const double x = __builtin_fma(-mu, z[r], d[r]);
+#if ADI_CYL_NT
         __builtin_nontemporal_store(x, out + base + (long)(r0 + r) * stride);
+#else
+        out[base + (long)(r0 + r) * stride] = x;
+#endif
     }
 }
 
@@ -448,7 +459,13 @@ __global__ __launch_bounds__(1024) void k_cyl_r_fast(
     for (int r = MI - 2; r >= 0; --r) d[r] = __builtin_fma(-T.cr(r), d[r + 1], d[r]) * T.ip(r);
     d[M - 1] = xS;
 #pragma unroll
-    for (int r = 0; r < M; ++r) __builtin_nontemporal_store(d[r], out + base + (long)(r0 + r) * stride);
+    for (int r = 0; r < M; ++r) {
+#if ADI_CYL_NT
+        __builtin_nontemporal_store(d[r], out + base + (long)(r0 + r) * stride);
+#else
+        out[base + (long)(r0 + r) * stride] = d[r];
+#endif
+    }
 }
 
 // elementwise pass used when a sweep degenerates (nphi == 1) or the grid is too long for the fast path

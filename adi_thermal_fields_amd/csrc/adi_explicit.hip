@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void k_explicit_v5(const double *__restrict__ 
                                                      double *__restrict__ R0, Lay L, double invdx2, double f,
                                                      int jslab, int ktiles, int ichunk, long ntiles, int i_begin,
                                                      int i_end, const double *__restrict__ wu = nullptr,
-                                                     double *__restrict__ part = nullptr, int i_org = 0, int n_line = 0)
+                                                     double *__restrict__ part = nullptr, int i_org = 0, int n_line = 0,
+                                                     int nt = 1)
 {
 #pragma clang fp contract(off)
     const int nx = L.nx, ny = L.ny, nz = L.nz;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void k_explicit_v5(const double *__restrict__ 
                 }
                 r1v = tc[r].y + f * ((L0 + L1) + L2);
             }
-            if (kin && rin) st_stream2(reinterpret_cast<double2 *>(R0 + q), make_double2(r0v, r1v));
+            if (kin && rin) st_stream2(reinterpret_cast<double2 *>(R0 + q), make_double2(r0v, r1v), nt != 0);
             if (DOTS) {
                 su[r].x = __builtin_fma(wa, r0v, su[r].x); su[r].y = __builtin_fma(wa, r1v, su[r].y);
                 sv[r].x = __builtin_fma(wb, r0v, sv[r].x); sv[r].y = __builtin_fma(wb, r1v, sv[r].y);
@@ -583,7 +584,7 @@ int adi_explicit_rhs_planes(const double *d_T, const uint8_t *d_flags, int nx, i
         const long ntiles = (long)nslab * nchunk * ((jslab + 1) / 2) * ktiles;
         hipLaunchKernelGGL(k_explicit_v5<2>, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
                            L, invdx2, f, jslab, ktiles, ichunk, ntiles, i_begin, i_end, (const double *)nullptr,
-                           (double *)nullptr, 0, 0);
+                           (double *)nullptr, 0, 0, store_policy_nt(L.nx, L.sx));
     } else {    // odd nz / unaligned views: one thread per cell
         const long cells = (long)np * ny * nz;
         hipLaunchKernelGGL(k_explicit_cell, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, as_stream(stream), d_T,
@@ -680,7 +681,7 @@ int adi_explicit_rhs_dots(const double *d_T, const uint8_t *d_flags, int nx, int
     const long ntiles = (long)nslab * nchunk * ((jslab + 1) / 2) * ktiles;
     hipLaunchKernelGGL((k_explicit_v5<2, true>), dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), d_T, d_flags, d_R0,
                        L, 1.0 / (dx * dx), dt * kappa * (1.0 - theta), jslab, ktiles, ichunk, ntiles, i_begin, i_end,
-                       d_weights, d_part, i_org, n_line);
+                       d_weights, d_part, i_org, n_line, store_policy_nt(L.nx, L.sx));
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }

@@ -74,7 +74,7 @@ __device__ __forceinline__ void contig_unit_general(
     double x[M];
     back_solve<M>(a, c, d, ip, xL, xS, x);
     if constexpr (COAL) {
-        coal_store<M>(out + wbase, strip, lane, x);
+        coal_store<M>(out + wbase, strip, lane, x, s.nt != 0);
     } else if (VEC) {
         if (active && r0 < n) {
             double2 *q = reinterpret_cast<double2 *>(out + base);
