@@ -11,7 +11,7 @@ import adi_thermal_fields_amd.adi3d_hip_coeff as adi
 dx = 5e-4
 mat = adi.Material(7800.0, 490.0, 54.0)
 alpha = mat.k / (mat.rho * mat.cp)
-for n in (256, 512):
+for n in (128, 192, 256, 512):
     grid = adi.Grid3D(n, n, n, dx, np.ones((n, n, n), bool))
     prm = adi.Params(200.0 * dx * dx / alpha, 0.5)
     packs = adi.precompute_coeff_packs_unified(grid, mat, robin_h=500.0)
