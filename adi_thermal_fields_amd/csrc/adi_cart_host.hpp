@@ -44,7 +44,7 @@ struct StridedPlan {
 // in a 512-thread workgroup; the GENERAL kernel keeps 8 rows per thread (register budget) on tiles of 16 or 32 of
 // the same lines, `ratio` of them per FAST tile.
 
-inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok, bool fused = false)
+inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok, bool fused = false, bool fused_exact = false)
 {
     StridedPlan P;
     const int n = g.n;
@@ -67,6 +67,11 @@ inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok,
         int exact = 0;
         if (!fused && !wide_ok && n >= 320 && !(n % 16 == 0 && ((n / 16) & (n / 16 - 1)) == 0))
             for (int m = 20; m <= 28 && !exact; m += 4)
+                if (n % m == 0 && (n / m == 16 || n / m == 32)) exact = m;
+        // ... and for the fused explicit + sweep kernel, which holds at most 16 rows per thread, 10 / 12 / 14 rows where they cut
+        // the line into exactly 16 or 32 segments (n = 160, 192, 224, 320, 384, 448; adi_sweep_strided_fx.hip, round 3)
+        if (fused && fused_exact && n >= 160 && !(n % 16 == 0 && ((n / 16) & (n / 16 - 1)) == 0))
+            for (int m = 10; m <= 14 && !exact; m += 2)
                 if (n % m == 0 && (n / m == 16 || n / m == 32)) exact = m;
         if (exact) { mf = exact; lf = 16; }
         else if (wide_ok && n % 16 == 0 && (n / 16 == 8 || n / 16 == 16 || n / 16 == 32)) { mf = n / 16; lf = 32; }   // Lpf = 16

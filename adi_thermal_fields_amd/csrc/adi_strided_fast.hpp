@@ -164,6 +164,11 @@ inline void launch_strided_fast(const StridedPlan &P, const double *in, const ui
                                                                st, fz);
 }
 
+// adi_sweep_strided_fx.hip: the fused kernel with 10 / 12 / 14 rows per thread (exact fits, no Dirichlet cells)
+void strided_fast_fused_exact(int mf, bool has_q, const StridedPlan &P, const double *in, const uint8_t *flags,
+                              const double *coeff, const double *qf, double *out, const LineGeom &g, const double *xlo,
+                              const double *xhi, SweepScal s, unsigned *queue, hipStream_t st, const Fuse &fz);
+
 // adi_sweep_strided_x.hip: launch_strided_fast<mf, ..., false> for mf = 20, 24, 28
 void strided_fast_exact(int mf, bool has_dir, bool has_q, const StridedPlan &P, const double *in, const uint8_t *flags,
                         const double *coeff, const uint8_t *dmask, const double *dval, const double *qf, double *out,

@@ -199,6 +199,8 @@ static void launch_strided(const StridedPlan &P, const double *in, const uint8_t
         else (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
         if (P.Mf == 20 || P.Mf == 24 || P.Mf == 28)      // exact fits: instantiated in adi_sweep_strided_x.hip
             strided_fast_exact(P.Mf, HAS_DIR, HAS_Q, P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
+        else if (P.Mf == 10 || P.Mf == 12 || P.Mf == 14)  // exact fits of the fused kernel (no Dirichlet cells): adi_sweep_strided_fx.hip
+            strided_fast_fused_exact(P.Mf, HAS_Q, P, in, flags, coeff, qf, out, g, xlo, xhi, s, queue, st, fz);
         else if (P.Mf == 32) launch_strided_fast<32, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         else if (P.Mf == 16) launch_strided_fast<16, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         else launch_strided_fast<8, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
@@ -226,7 +228,7 @@ static void strided_sweep_t(const SweepArgs &a, const Lay &L, const LineGeom &g,
                             const double *xlo, const double *xhi, void *work, size_t work_bytes, hipStream_t st,
                             const Fuse *fzp)
 {
-    StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr, false, fzp != nullptr);
+    StridedPlan P = strided_plan(g, s.sparse != 0 && work != nullptr, false, fzp != nullptr, fzp != nullptr && !HAS_DIR);
     unsigned *queue = nullptr;
     if (P.Mf && use_fast(s, work, work_bytes, P.ntiles_f)) queue = (unsigned *)work;
     else if (P.Mf) P = strided_plan(g, false, false);
