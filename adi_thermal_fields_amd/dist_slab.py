@@ -36,7 +36,20 @@ import threading
 import numpy as np
 import torch
 
-__all__ = ['SlabStepper', 'TorchDistComm', 'LocalComm', 'LoopbackComm', 'SelfLoopDistComm', 'HipEngine', 'split_planes']
+__all__ = ['SlabStepper', 'TorchDistComm', 'LocalComm', 'LoopbackComm', 'SelfLoopDistComm', 'HipEngine', 'split_planes',
+           'rccl_env_defaults']
+
+
+def rccl_env_defaults():
+    """Environment a rank wants BEFORE `init_process_group('nccl')` (setdefault: the caller's own settings win).
+    * HSA_ENABLE_IPC_MODE_LEGACY=0: the hosts of this pool only support dmabuf IPC.
+    * TORCH_NCCL_HIGH_PRIORITY=1: torch runs RCCL kernels on an internal stream; at normal priority HIP may map that
+      stream onto the same hardware queue as the stream the sweeps run on (measured: rocprofv3 showed both on one HSA
+      queue), and then a halo send/recv posted "beside" a sweep runs after it instead -- nothing overlaps.  High-priority
+      streams get queues of their own: per-rank step over the RCCL self-loop 1.65 -> 1.59 ms."""
+    import os
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '1')
 
 
 def split_planes(nx, world):
@@ -470,6 +483,8 @@ class SlabStepper:
     """One rank's slab.  step(T) takes / returns the LOCAL (nxl, ny, nz) field (DeviceField, torch tensor or
     NumPy array); the state stays in HBM when fed back what step() returned."""
 
+    _comm_priority = -1           # the side stream is a high-priority one: a HSA queue of its own (see rccl_env_defaults)
+
     def __init__(self, mask_local, dx, mat, params, Tinf=0.0, dir_mask=None, dir_value=None, neumann=None,
                  robin_h=None, comm=None, engine=None):
         self.engine = engine or HipEngine()
@@ -702,7 +717,7 @@ class SlabStepper:
         self._use_streams = (E.device.type == 'cuda') and isinstance(self.comm, TorchDistComm) \
             and not self._no_overlap
         if self._use_streams and self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=E.device)
+            self._comm_stream = torch.cuda.Stream(device=E.device, priority=self._comm_priority)
         return self._use_streams
 
     def _window_guess(self, gam):
@@ -1095,17 +1110,10 @@ class SlabStepper:
                                     plan['xlo'], plan['xhi'])
                 E.deferred_exact_coef(plan['dx'], plan['xlo'], plan['xhi'], self.nlines, plan['ulo'], plan['uhi'])
             else:
-                if streams:
-                    ev0 = torch.cuda.Event(); ev0.record(main)
-                    with torch.cuda.stream(self._comm_stream):
-                        self._comm_stream.wait_event(ev0)
-                        self.comm.exchange_planes(Bi[0], Bi[nl - 1], plan['prev_last'].view(self.ny, self.nz),
-                                                  plan['next_first'].view(self.ny, self.nz))
-                        ev1 = torch.cuda.Event(); ev1.record(self._comm_stream)
-                    main.wait_event(ev1)
-                else:
-                    self.comm.exchange_planes(Bi[0], Bi[nl - 1], plan['prev_last'].view(self.ny, self.nz),
-                                              plan['next_first'].view(self.ny, self.nz))
+                # issued on the main stream: nothing can run beside this exchange (the next kernel needs the planes), and
+                # every hop through another stream is a cross-queue dependency of 10 - 20 us on the critical path
+                self.comm.exchange_planes(Bi[0], Bi[nl - 1], plan['prev_last'].view(self.ny, self.nz),
+                                          plan['next_first'].view(self.ny, self.nz))
                 first, last = self.rank == 0, self.rank == self.world - 1
                 E.interface_deferred(Bi[0], Bi[nl - 1], None if first else plan['prev_last'],
                                      None if last else plan['next_first'], plan['dfr']['omega'], self.nlines, plan['ulo'],

@@ -347,7 +347,8 @@ def main(argv=None):
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     if world > 1 or force_dist:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        from adi_thermal_fields_amd.dist_slab import rccl_env_defaults
+        rccl_env_defaults()                      # dmabuf IPC; RCCL kernels on a hardware queue of their own
         if force_dist:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
             dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)

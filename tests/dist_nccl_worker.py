@@ -17,7 +17,8 @@ sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
 
 def main():
     rank = int(os.environ['RANK']); world = int(os.environ['WORLD_SIZE']); local = int(os.environ.get('LOCAL_RANK', rank))
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    from adi_thermal_fields_amd.dist_slab import rccl_env_defaults
+    rccl_env_defaults()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist.init_process_group('nccl', device_id=dev)

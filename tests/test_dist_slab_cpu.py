@@ -256,3 +256,15 @@ def test_split_planes_even():
     for nx, w in ((70, 3), (513, 4), (12, 5)):
         s = split_planes(nx, w)
         assert sum(s) == nx and all(v > 0 for v in s) and all(v % 2 == 0 for v in s[:-1])
+
+
+def test_rccl_env_defaults_keep_the_callers_settings(monkeypatch):
+    from adi_thermal_fields_amd import dist_slab
+    monkeypatch.delenv('HSA_ENABLE_IPC_MODE_LEGACY', raising=False)
+    monkeypatch.setenv('TORCH_NCCL_HIGH_PRIORITY', '0')
+    dist_slab.rccl_env_defaults()
+    import os
+    assert os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and os.environ['TORCH_NCCL_HIGH_PRIORITY'] == '0'
+    monkeypatch.delenv('TORCH_NCCL_HIGH_PRIORITY')
+    dist_slab.rccl_env_defaults()
+    assert os.environ['TORCH_NCCL_HIGH_PRIORITY'] == '1'

@@ -262,7 +262,7 @@ def test_slab_step_over_real_rccl_self_loop():
     import adi_thermal_fields_amd.adi3d_hip_coeff as hip
     from adi_thermal_fields_amd import dist_slab
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist_slab.rccl_env_defaults()
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
