@@ -40,6 +40,7 @@ SIGNATURES = {
     'adi_device_count': (c_int, [c_int_p]),
     'adi_device_info': (c_int, [c_int, ctypes.c_char_p, c_int_p, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     'adi_recommended_plane_stride': (ctypes.c_long, [c_int, c_int]),
+    'adi_recommended_dims': (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'adi_exposed_mask': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p, c_void_p]),
     'adi_build_coeffs': (c_int, [c_void_p, c_int, c_int, c_int, c_long, c_double, c_double, c_double,
                                  c_int_p, c_double_p, c_void_pp, c_int_p, c_double_p, c_void_pp,

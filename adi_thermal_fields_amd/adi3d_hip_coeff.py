@@ -62,13 +62,30 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-class Layout:
-    """Device layout of a (nx, ny, nz) grid: element (i, j, k) at i*sx + j*nz + k."""
+def recommended_dims(nx, ny, nz):
+    """physical extents the kernels want for a logical (nx, ny, nz) grid (adi_recommended_dims)"""
+    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    check(lib.adi_recommended_dims(int(nx), int(ny), int(nz), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return a.value, b.value, c.value
 
-    def __init__(self, nx, ny, nz, sx=None):
+
+class Layout:
+    """Device layout of a (nx, ny, nz) grid: element (i, j, k) at i*sx + j*pz + k inside a PHYSICAL box (px, py, pz) >= the
+    logical one.  Ragged extents (257 rows, nz = 250) would send every line to the GENERAL kernels, so fields are allocated
+    with the extents adi_recommended_dims() picks; the cells outside the logical box are off-mask (identity rows, never
+    read by an in-mask cell: the reference treats the edge of the domain and an off-mask neighbour alike,
+    adi3d_numba_coeff.py:38-55), the kernels are launched on the physical box (`pd`), and everything the caller sees --
+    shapes, NumPy arrays, DeviceField indexing -- is the logical box.  Layouts made with an explicit plane stride `sx`
+    (slabs, views of foreign tensors) are never padded unless `phys` says so."""
+
+    def __init__(self, nx, ny, nz, sx=None, phys=None):
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
-        self.sx = int(lib.adi_recommended_plane_stride(self.ny, self.nz)) if sx is None else int(sx)
-        assert self.sx >= self.ny * self.nz
+        if phys is None:
+            phys = recommended_dims(nx, ny, nz) if sx is None else (self.nx, self.ny, self.nz)
+        self.px, self.py, self.pz = (int(v) for v in phys)
+        assert self.px >= self.nx and self.py >= self.ny and self.pz >= self.nz
+        self.sx = int(lib.adi_recommended_plane_stride(self.py, self.pz)) if sx is None else int(sx)
+        assert self.sx >= self.py * self.pz
 
     @property
     def shape(self):
@@ -76,11 +93,20 @@ class Layout:
 
     @property
     def strides(self):
-        return (self.sx, self.nz, 1)
+        return (self.sx, self.pz, 1)
+
+    @property
+    def pd(self):
+        """(nx, ny, nz, plane_stride) as the C ABI takes them: the physical box"""
+        return (self.px, self.py, self.pz, self.sx)
+
+    @property
+    def padded(self):
+        return (self.px, self.py, self.pz) != (self.nx, self.ny, self.nz)
 
     @property
     def numel_padded(self):
-        return self.nx * self.sx
+        return self.px * self.sx
 
     def empty(self, dtype=torch.float64, zero=False):
         buf = (torch.zeros if zero else torch.empty)(self.numel_padded, dtype=dtype, device=_device())
@@ -88,7 +114,12 @@ class Layout:
 
     def is_native(self, t):
         return (isinstance(t, torch.Tensor) and t.is_cuda and tuple(t.shape) == self.shape
-                and tuple(t.stride()) == self.strides and t.storage_offset() == 0)
+                and tuple(t.stride()) == self.strides and t.storage_offset() == 0
+                and t.untyped_storage().nbytes() >= self.numel_padded * t.element_size())
+
+    def _fresh(self, dtype):
+        # masks / flags are read over the whole physical box and the plane padding; fields over the physical box
+        return self.empty(dtype, zero=(self.padded or (dtype == torch.uint8 and self.sx != self.ny * self.nz)))
 
     def to_layout(self, a, dtype):
         """host array / tensor / DeviceField -> tensor in this layout (a copy unless already native)."""
@@ -101,7 +132,7 @@ class Layout:
             if dtype == torch.uint8 and src.dtype == torch.bool:
                 src = src.to(torch.uint8)
             assert tuple(src.shape) == self.shape, (tuple(src.shape), self.shape)
-            out = self.empty(dtype, zero=(dtype == torch.uint8 and self.sx != self.ny * self.nz))
+            out = self._fresh(dtype)
             out.copy_(src.to(dtype) if src.dtype != dtype else src)
             return out
         arr = np.asarray(a)
@@ -110,11 +141,18 @@ class Layout:
         else:
             arr = np.ascontiguousarray(arr, dtype=np.float64)   # fp32 fields are up-cast (waam --precision float32)
         assert tuple(arr.shape) == self.shape, (tuple(arr.shape), self.shape)
-        out = self.empty(dtype, zero=(dtype == torch.uint8 and self.sx != self.ny * self.nz))
-        # every plane of the dense host array into its (padded) device plane: ONE 2-D DMA, no staging tensor
+        out = self._fresh(dtype)
         es = arr.itemsize
-        check(lib.adi_copy_planes(_p(out), self.sx * es, ctypes.c_void_p(arr.ctypes.data), self.ny * self.nz * es,
-                                  self.ny * self.nz * es, self.nx, 1, _stream()))
+        if self.pz == self.nz:
+            # every plane of the dense host array into its (padded) device plane: ONE 2-D DMA, no staging tensor
+            check(lib.adi_copy_planes(_p(out), self.sx * es, ctypes.c_void_p(arr.ctypes.data), self.ny * self.nz * es,
+                                      self.ny * self.nz * es, self.nx, 1, _stream()))
+        else:
+            # padded rows: one dense DMA into a staging tensor, rows spread on the device
+            stage = torch.empty(self.shape, dtype=dtype, device=_device())
+            n = arr.size * es
+            check(lib.adi_copy_planes(_p(stage), n, ctypes.c_void_p(arr.ctypes.data), n, n, 1, 1, _stream()))
+            out.copy_(stage)
         torch.cuda.current_stream().synchronize()     # the caller may touch its array as soon as we return
         return out
 
@@ -126,10 +164,27 @@ class Layout:
         assert self.is_native(t)
         host = torch.empty(self.shape, dtype=t.dtype, pin_memory=True)
         es = t.element_size()
-        check(lib.adi_copy_planes(ctypes.c_void_p(host.data_ptr()), self.ny * self.nz * es, _p(t), self.sx * es,
-                                  self.ny * self.nz * es, self.nx, 0, _stream()))
+        if self.pz == self.nz:
+            check(lib.adi_copy_planes(ctypes.c_void_p(host.data_ptr()), self.ny * self.nz * es, _p(t), self.sx * es,
+                                      self.ny * self.nz * es, self.nx, 0, _stream()))
+        else:
+            stage = t.contiguous()                    # padded rows: gathered on the device, one dense DMA
+            n = stage.numel() * es
+            check(lib.adi_copy_planes(ctypes.c_void_p(host.data_ptr()), n, _p(stage), n, n, 1, 0, _stream()))
         torch.cuda.current_stream().synchronize()
         return host.numpy()
+
+    @staticmethod
+    def of(t):
+        """the layout a 3-D device tensor is in, or None when it is not of this family (rows contiguous, offset 0)"""
+        if not (isinstance(t, torch.Tensor) and t.dim() == 3 and t.storage_offset() == 0 and t.stride(2) == 1
+                and t.stride(1) >= t.shape[2] and t.stride(0) >= t.stride(1) * t.shape[1]):
+            return None
+        nx, ny, nz = t.shape
+        sx, pz = t.stride(0), t.stride(1)
+        py = max(ny, min(sx // pz, recommended_dims(nx, ny, nz)[1])) if pz else ny
+        px = max(nx, t.untyped_storage().nbytes() // t.element_size() // sx) if sx else nx
+        return Layout(nx, ny, nz, sx=sx, phys=(px, py, pz))
 
 
 class DeviceField:
@@ -146,8 +201,7 @@ class DeviceField:
     dtype = np.dtype(np.float64)
 
     def get(self):
-        L = Layout(*tuple(self.t.shape), sx=self.t.stride(0)) if self.t.dim() == 3 and self.t.stride(1) == self.t.shape[2] \
-            and self.t.stride(2) == 1 and self.t.stride(0) >= self.t.shape[1] * self.t.shape[2] else None
+        L = Layout.of(self.t)
         if L is not None and L.is_native(self.t):
             return L.to_host(self.t)
         return self.t.cpu().contiguous().numpy()
@@ -159,10 +213,11 @@ class DeviceField:
     def copy(self):
         if self.t.is_contiguous() or self.t.storage_offset() != 0:
             return DeviceField(self.t.clone())
-        t = torch.empty(self.t.shape[0] * self.t.stride(0), dtype=self.t.dtype, device=self.t.device) \
-            .as_strided(self.t.shape, self.t.stride())
-        t.copy_(self.t)
-        return DeviceField(t)
+        # the whole storage: plane padding and the cells of the physical box outside the logical one travel along
+        n = self.t.untyped_storage().nbytes() // self.t.element_size()
+        flat = torch.empty(n, dtype=self.t.dtype, device=self.t.device)
+        flat.copy_(self.t.as_strided((n,), (1,)))
+        return DeviceField(flat.as_strided(self.t.shape, self.t.stride()))
 
     def astype(self, dtype, copy=True):
         return self.get().astype(dtype, copy=False)
@@ -211,7 +266,7 @@ def to_device(T):
     if isinstance(T, DeviceField):
         return T.copy()
     t = Layout(*tuple(T.shape)).to_layout(T, torch.float64)
-    return DeviceField(t.clone() if (isinstance(T, torch.Tensor) and t is T) else t)
+    return DeviceField(t).copy() if (isinstance(T, torch.Tensor) and t is T) else DeviceField(t)
 
 
 class Grid3D:
@@ -256,8 +311,8 @@ class Grid3D:
         """neighbour flags of the device mask, in place (the buffer is zero-filled once: plane padding)"""
         if self._d_flags is None:
             self._d_flags = self.layout.empty(torch.uint8, zero=True)
-        k_end = self.nz if k_end is None else k_end
-        check(lib.adi_build_nbr_flags_planes(_p(self._d_mask), self.nx, self.ny, self.nz, self.sx, _p(self._d_flags),
+        k_end = self.layout.pz if k_end is None else k_end
+        check(lib.adi_build_nbr_flags_planes(_p(self._d_mask), *self.layout.pd, _p(self._d_flags),
                                              int(k_begin), int(k_end), _stream()))
         self.mask_version = next(_MASK_VERSIONS)
         self._all_solid = None
@@ -266,12 +321,13 @@ class Grid3D:
     def all_solid(self):
         """hint for the kernels (no surface inside the box); evaluated on demand -- it costs a host synchronisation"""
         if self._all_solid is None:
-            self._all_solid = bool((self._d_mask != 0).all().item()) if self._d_mask is not None else False
+            self._all_solid = (not self.layout.padded and bool((self._d_mask != 0).all().item())) \
+                if self._d_mask is not None else False       # (a padded box has off-mask cells: never "all solid")
         return self._all_solid
 
     @all_solid.setter
     def all_solid(self, v):
-        self._all_solid = None if v is None else bool(v)
+        self._all_solid = None if v is None else (bool(v) and not self.layout.padded)
 
     def set_mask_device(self, d_mask, k_begin=0, k_end=None, all_solid=None):
         """`grid.mask = ...` for a mask that already lives on the device (uint8 tensor in the grid's layout, e.g.
@@ -284,7 +340,7 @@ class Grid3D:
         self._mask = None
         self._device_mask = True
         self._rebuild_flags(k_begin, k_end)
-        self._all_solid = all_solid
+        self._all_solid = None if all_solid is None else (bool(all_solid) and not self.layout.padded)
         return self._d_mask
 
     def sync_mask(self):
@@ -301,7 +357,7 @@ class Grid3D:
             return self._d_mask
         self._d_mask = new
         self._rebuild_flags()
-        self._all_solid = bool(np.asarray(self._mask).all())     # hint for the kernels: no surface inside the box
+        self._all_solid = bool(np.asarray(self._mask).all()) and not self.layout.padded   # hint for the kernels: no surface inside the (physical) box
         return self._d_mask
 
     @property
@@ -320,7 +376,7 @@ class Grid3D:
             wb = 0
             for ax in range(3):
                 b = ctypes.c_size_t(0)
-                check(lib.adi_sweep_workspace_bytes(ax, self.nx, self.ny, self.nz, self.sx, ctypes.byref(b)))
+                check(lib.adi_sweep_workspace_bytes(ax, *self.layout.pd, ctypes.byref(b)))
                 wb = max(wb, b.value)
             work = torch.empty(wb, dtype=torch.uint8, device=_device()) if wb else None
             self._scratch = (fields, work, wb)
@@ -489,7 +545,7 @@ def precompute_coeff_packs_unified(grid, mat, dir_mask=None, dir_value=None, neu
     qm = (ctypes.c_int * 6)(*[s[0] for s in q_specs])
     qs = (ctypes.c_double * 6)(*[s[1] for s in q_specs])
     qf = ptr_array([s[2].data_ptr() if s[2] is not None else None for s in q_specs])
-    check(lib.adi_build_coeffs(_p(d_mask), grid.nx, grid.ny, grid.nz, grid.sx, grid.dx, mat.rho, mat.cp,
+    check(lib.adi_build_coeffs(_p(d_mask), *grid.layout.pd, grid.dx, mat.rho, mat.cp,
                                hm, hs, hf, qm, qs, qf,
                                ptr_array([c.data_ptr() for c in coeff]), ptr_array([q.data_ptr() for q in qflux]),
                                _stream()))
@@ -502,7 +558,7 @@ def precompute_coeff_packs_unified(grid, mat, dir_mask=None, dir_value=None, neu
         if dir_value is None:
             d_dv = L.empty(zero=True)                                   # :75-76
         elif np.isscalar(dir_value):
-            d_dv = L.empty()
+            d_dv = L.empty(zero=L.padded)
             d_dv.fill_(float(dir_value))                                # :77-78
         else:
             d_dv = L.to_layout(dir_value, torch.float64)
@@ -553,7 +609,7 @@ def adi_explicit_rhs(Tn, grid, mat, params):
     t, kind = _as_state(Tn, grid)
     kappa, _ = _gam(grid, mat, params)
     out = grid.layout.empty()
-    check(lib.adi_explicit_rhs(_p(t), _p(grid.d_flags), grid.nx, grid.ny, grid.nz, grid.sx, grid.dx, params.dt,
+    check(lib.adi_explicit_rhs(_p(t), _p(grid.d_flags), *grid.layout.pd, grid.dx, params.dt,
                                kappa, params.theta, _p(out), _stream()))
     return _wrap(out, kind)
 
@@ -609,7 +665,7 @@ def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None, 
     sp = _sparse_arg(grid, pack, dense)
     nf = _NoFallback(grid, pack, 'sweep', axis, v, sp, work)
     check(lib.adi_sweep(axis, v, _p(t_in), _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
-                        _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
+                        _p(pack.d_dir_val), _p(pack.d_qflux), *grid.layout.pd,
                         sp | nf.bit, params.theta,
                         gam, params.dt, float(Tinf), _p(t_out),
                         _p(xlo), _p(xhi), _fc_arg(grid, pack, sp),
@@ -619,7 +675,7 @@ def _sweep_into(axis, t_in, t_out, grid, mat, params, pack, Tinf, variant=None, 
 
 def fused_supported(grid, cond_pass=False):
     """explicit stage folded into the axis-0 sweep (adi_explicit_sweep0, ABI v7) available for this grid"""
-    return bool(lib.adi_explicit_fused_supported(grid.nx, grid.ny, grid.nz, grid.sx, 1 if cond_pass else 0))
+    return bool(lib.adi_explicit_fused_supported(*grid.layout.pd, 1 if cond_pass else 0))
 
 
 def valid_range(t):
@@ -639,7 +695,7 @@ def _explicit_sweep0_into(t, t_out, grid, mat, params, pack, Tinf, variant=None,
     sp = _sparse_arg(grid, pack, dense)
     nf = _NoFallback(grid, pack, 'fused', 0, v, sp, work)
     check(lib.adi_explicit_sweep0(v, _p(t), vlo, vhi, _p(grid.d_flags), _p(pack.d_coeff), _p(pack.d_dir_mask),
-                                  _p(pack.d_dir_val), _p(pack.d_qflux), grid.nx, grid.ny, grid.nz, grid.sx,
+                                  _p(pack.d_dir_val), _p(pack.d_qflux), *grid.layout.pd,
                                   sp | nf.bit, grid.dx, params.dt, kappa, params.theta,
                                   float(Tinf), _p(t_out), None, None, _fc_arg(grid, pack, sp), _p(work), wb, _stream()))
     nf.learn()
@@ -690,7 +746,7 @@ def adi_step_hip_coeff(Tn, grid, mat, params, packs, Tinf=0.0):
     if fused_supported(grid):
         _explicit_sweep0_into(t, tb, grid, mat, params, packx, Tinf)
     else:
-        check(lib.adi_explicit_rhs(_p(t), _p(grid.d_flags), grid.nx, grid.ny, grid.nz, grid.sx, grid.dx, params.dt,
+        check(lib.adi_explicit_rhs(_p(t), _p(grid.d_flags), *grid.layout.pd, grid.dx, params.dt,
                                    kappa, params.theta, _p(ta), _stream()))
         _sweep_into(0, ta, tb, grid, mat, params, packx, Tinf)
     _sweep_into(1, tb, ta, grid, mat, params, packy, Tinf)
@@ -734,9 +790,9 @@ def exposed_faces_per_layer(mask_or_grid, faces=_LATERAL):
         m = np.asarray(mask_or_grid)
         g = Grid3D(m.shape[0], m.shape[1], m.shape[2], 1.0, m)
     bits = sum(1 << FACES.index(f) for f in set(faces))
-    counts = torch.empty(g.nz, dtype=torch.int64, device=_device())
-    check(lib.adi_count_exposed_faces(_p(g.d_flags), g.nx, g.ny, g.nz, g.sx, bits, _p(counts), _stream()))
-    return counts.cpu().numpy()
+    counts = torch.empty(g.layout.pz, dtype=torch.int64, device=_device())
+    check(lib.adi_count_exposed_faces(_p(g.d_flags), *g.layout.pd, bits, _p(counts), _stream()))
+    return counts[:g.nz].cpu().numpy()                # (the planes of the physical box beyond nz hold no in-mask cell)
 
 
 def count_exposed_faces(mask2d):
@@ -765,7 +821,7 @@ def birth_planes(T, d_active, d_full, grid, k_begin, k_end, Ts, count=None):
     assert L.is_native(d_active) and L.is_native(d_full) and L.is_native(T.t)
     if count is None:
         count = torch.empty(1, dtype=torch.int64, device=T.t.device)
-    check(lib.adi_birth_planes(_p(T.t), _p(d_active), _p(d_full), grid.nx, grid.ny, grid.nz, grid.sx, int(k_begin),
+    check(lib.adi_birth_planes(_p(T.t), _p(d_active), _p(d_full), *grid.layout.pd, int(k_begin),
                                int(k_end), float(Ts), _p(count), _stream()))
     return count
 
@@ -807,7 +863,7 @@ class BirthPacks:
         g, m = self.grid, self.mat
         k0, k1 = max(0, int(k_begin)), min(g.nz, int(k_end))
         hm, hs, hf, qm, qs, qf = self._args
-        check(lib.adi_build_coeffs_planes(_p(g.d_mask), g.nx, g.ny, g.nz, g.sx, g.dx, m.rho, m.cp, hm, hs, hf, qm, qs, qf,
+        check(lib.adi_build_coeffs_planes(_p(g.d_mask), *g.layout.pd, g.dx, m.rho, m.cp, hm, hs, hf, qm, qs, qf,
                                           ptr_array([c.data_ptr() for c in self.coeff]),
                                           ptr_array([q.data_ptr() for q in self.qflux]), k0, k1, _stream()))
         for a, p in enumerate(self.packs):
@@ -853,7 +909,7 @@ class StagedStepper:
         if self.fused:
             _explicit_sweep0_into(t, tb, g, self.mat, prm, self.packs[0], self.Tinf)
         else:
-            check(lib.adi_explicit_rhs(_p(t), _p(g.d_flags), g.nx, g.ny, g.nz, g.sx, g.dx, prm.dt, kappa, prm.theta,
+            check(lib.adi_explicit_rhs(_p(t), _p(g.d_flags), *g.layout.pd, g.dx, prm.dt, kappa, prm.theta,
                                        _p(ta), _stream()))
             self.sweep_into(0, ta, tb)
         self.sweep_into(1, tb, ta)
@@ -917,7 +973,7 @@ class StagedStepper:
         if self.fused:
             _explicit_sweep0_into(t, tb, g, self.mat, prm, self.packs[0], self.Tinf)
         else:
-            check(lib.adi_explicit_rhs(_p(t), _p(g.d_flags), g.nx, g.ny, g.nz, g.sx, g.dx, prm.dt, kappa, prm.theta,
+            check(lib.adi_explicit_rhs(_p(t), _p(g.d_flags), *g.layout.pd, g.dx, prm.dt, kappa, prm.theta,
                                        _p(ta), _stream()))
             mark()
             self.sweep_into(0, ta, tb)

@@ -33,7 +33,7 @@ class GridCyl:  # adi3d_cyl_phi_v3.py:33-43
         self.r_imh = self.r - 0.5 * self.dr
         self.r_iph = self.r + 0.5 * self.dr
         self.r_outer_face = self.r_iph[-1]
-        self.layout = Layout(self.nr, self.nphi, self.nz)
+        self.layout = Layout(self.nr, self.nphi, self.nz, phys=(self.nr, self.nphi, self.nz))   # (no padded extents: the phi lines are periodic)
         self._plans = {}
         self._scratch = None
 

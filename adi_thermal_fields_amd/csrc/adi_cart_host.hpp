@@ -145,6 +145,47 @@ inline int make_lay(int nx, int ny, int nz, long plane_stride, Lay *L)
     return ADI_OK;
 }
 
+// rows per lane of the contiguous FAST kernel for lines of n rows (`m_general`: rows per lane of the GENERAL kernel the
+// launcher was instantiated with); 0: the line has no FAST form.  launch_contig and the padding model below use it.
+inline int contig_fast_rows(int n, int m_general)
+{
+    const auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (n >= 256 && !(n % 16 == 0 && pow2(n / 16)))
+        for (int m = 20; m <= 28; m += 4)
+            if (n % m == 0 && pow2(n / m) && n / m >= 8 && n / m <= 64) return m;
+    if (n >= 128 && n % 16 == 0 && n / 16 <= 64) return 16;
+    if (n >= 64 && n % 8 == 0 && n / 8 <= 64 && m_general < 8) return 8;
+    return m_general;
+}
+inline int contig_rows_per_lane(int n) { return n <= 128 ? 2 : (n <= 256 ? 4 : (n <= 512 ? 8 : 16)); }
+
+// Padding model (adi_recommended_dims): the fraction of the lanes / segment slots of a workgroup that a line of n rows
+// along `axis` fills -- 1 where a row count cuts it into a power-of-two number of segments, 17/32 for 272 rows on the FAST
+// kernels -- times, where only the GENERAL kernels take the line, their measured rate relative to the FAST ones
+// (scripts/perf_map.py on 250^3 / 300^3 against 256^3 / 320^3: explicit + axis-0 as two GENERAL-path kernels 0.38 of the
+// fused FAST kernel, the other two sweeps 0.5).
+inline double line_fill(int axis, int n, int ny, int nz)
+{
+    static const double general[3] = {0.38, 0.5, 0.5};
+    const int mg = axis == 2 ? contig_rows_per_lane(n) : strided_rows_per_thread(n);
+    const int sg = (n + mg - 1) / mg;
+    const double gen = general[axis] * sg / next_pow2(sg);
+    if (n < 64 || n > kMaxFastLine) return gen;
+    if (axis == 2) {
+        const int m = contig_fast_rows(n, contig_rows_per_lane(n));
+        if (n % m != 0 || m < 8) return gen;
+        return (double)(n / m) / next_pow2(n / m);
+    }
+    if (nz % 16 != 0) return gen;                        // the strided FAST tiles are 16 whole lines wide
+    Lay L;
+    L.nx = axis == 0 ? n : 64; L.ny = axis == 1 ? n : ny; L.nz = nz; L.sx = (long)L.ny * L.nz;
+    long inner = 1;
+    const LineGeom g = line_geom(axis, L, &inner);
+    const StridedPlan P = strided_plan(g, true, false, axis == 0, axis == 0);
+    if (!P.Mf) return gen;
+    return (double)(n / P.Mf) / P.Lpf;
+}
+
 inline unsigned cell_blocks(const Lay &L) { return (unsigned)(((long)L.nx * L.ny * L.nz + 255) / 256); }
 
 inline int variant_flags(int variant, bool *has_dir, bool *has_q)

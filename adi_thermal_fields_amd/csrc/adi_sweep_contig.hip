@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256) void k_sweep_contig(
 // ------------------------------------------------------------------------------------------------
 // host-side launch logic
 // ------------------------------------------------------------------------------------------------
-static int contig_rows_per_lane(int n) { return n <= 128 ? 2 : (n <= 256 ? 4 : (n <= 512 ? 8 : 16)); }
 
 
 template <int M, bool HAS_DIR, bool HAS_Q>
@@ -144,15 +143,7 @@ static void launch_contig(const double *in, const uint8_t *flags, const double *
     // lanes, 37 % of every wave padding; 209 against 270 Gcell/s at nz = 256).  Where 20, 24 or 28 rows per lane cut the
     // line into exactly 16 or 32 segments the FAST kernel takes that many (n = 320, 384, 448, 640, 768, 896; lines beyond
     // kMaxFastLine = 1024 rows never get here: sweep_entry sends them to the thread-per-line kernel)
-    int Mf = M;
-    const auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    int exact = 0;
-    if (n >= 256 && !(n % 16 == 0 && pow2(n / 16)))
-        for (int m = 20; m <= 28 && !exact; m += 4)
-            if (n % m == 0 && pow2(n / m) && n / m >= 8 && n / m <= 64) exact = m;
-    if (exact) Mf = exact;
-    else if (n >= 128 && n % 16 == 0 && n / 16 <= 64) Mf = 16;
-    else if (n >= 64 && n % 8 == 0 && n / 8 <= 64 && M < 8) Mf = 8;
+    const int Mf = contig_fast_rows(n, M);
     const int lwf = 64 / next_pow2((n + Mf - 1) / Mf);
     const long nunits_f = (nlines + lwf - 1) / lwf;
     const bool fast = use_fast(s, work, work_bytes, nunits_f) && (n % Mf == 0) && (lwf % lw == 0);

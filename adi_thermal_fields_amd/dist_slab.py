@@ -225,7 +225,9 @@ class HipEngine:
         return self._stream_ptr if self._stream_ptr is not None else self.hip._stream()
 
     def layout(self, nx, ny, nz, sx=None):
-        return self.hip.Layout(nx, ny, nz, sx)
+        # slabs are never padded to friendlier extents (Layout's default for whole grids): a slab's extended arrays, its
+        # halo planes and the sub-boxes the chunked passes address all share one plane stride
+        return self.hip.Layout(nx, ny, nz, sx, phys=(nx, ny, nz))
 
     def vec(self, n):
         return torch.empty(n, dtype=torch.float64, device=self.device)

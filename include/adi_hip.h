@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 15
+#define ADI_ABI_VERSION 16
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -77,6 +77,15 @@ int         adi_copy_planes(void *dst, size_t dst_pitch, const void *src, size_t
  * wants for a given (ny, nz).  Per-line arrays (d_xlo, d_xhi, d_cond) are dense.
  * ---------------------------------------------------------------------------------------------- */
 long adi_recommended_plane_stride(int ny, int nz);
+
+/* Physical extents the library recommends for a logical (nx, ny, nz) grid (ABI v16): each >= the logical extent, chosen
+ * per axis among the logical length and the next few multiples of 16 so that the lines fill the FAST kernels' workgroups
+ * (a 257-row line runs on the GENERAL kernels, a 272-row one on the FAST ones).  The caller allocates fields with the
+ * physical extents (plane stride from adi_recommended_plane_stride(*py, *pz)), marks every cell outside the logical box
+ * off-mask -- off-mask cells are identity rows and are never read by an in-mask cell, so the results inside the logical box
+ * are those of the logical grid (the reference treats the edge of the domain and an off-mask neighbour alike,
+ * adi3d_numba_coeff.py:38-55) -- and passes the physical extents to every entry point.  adi3d_hip_coeff.Layout does this. */
+int adi_recommended_dims(int nx, int ny, int nz, int *px, int *py, int *pz);
 
 /* exposed_mask(mask, face): adi3d_numba_coeff.py:38-55 / adi3d_gpu_coeff.py:31-48 */
 int adi_exposed_mask(const uint8_t *d_mask, int nx, int ny, int nz, long plane_stride, int face,
