@@ -224,9 +224,14 @@ class HipEngine:
         """the hipStream_t every kernel of this engine is launched on: torch's current stream, looked up once per step"""
         return self._stream_ptr if self._stream_ptr is not None else self.hip._stream()
 
+    def plane_dims(self, ny, nz):
+        """physical (ny, nz) of a slab's planes: adi_recommended_dims for a box with long lines along axis 0 (whatever the slab
+        thickness of this rank: all ranks must agree)"""
+        return tuple(self.hip.recommended_dims(64, ny, nz)[1:])
+
     def layout(self, nx, ny, nz, sx=None):
-        # slabs are never padded to friendlier extents (Layout's default for whole grids): a slab's extended arrays, its
-        # halo planes and the sub-boxes the chunked passes address all share one plane stride
+        # no padding at this level (Layout's default for whole grids): the stepper pads the planes of a slab itself
+        # (SlabStepper: plane_dims), and its extended arrays, halo planes and sub-boxes all share one plane stride
         return self.hip.Layout(nx, ny, nz, sx, phys=(nx, ny, nz))
 
     def vec(self, n):
@@ -495,8 +500,14 @@ class SlabStepper:
         self.mat, self.params, self.Tinf, self.dx = mat, params, float(Tinf), float(dx)
         self._bc = dict(dir_mask=dir_mask, dir_value=dir_value, neumann=neumann, robin_h=robin_h)
         mask_local = np.asarray(mask_local).astype(np.bool_)
-        self.nxl, self.ny, self.nz = mask_local.shape
         E = self.engine
+        # Padded planes: a ragged (ny, nz) would send every strided line to the GENERAL kernels (adi_recommended_dims, DESIGN.md
+        # section 2), so every internal array of the slab has planes of (self.ny, self.nz) >= the caller's (self.lny, self.lnz);
+        # the cells beyond are off-mask, the planes that travel are the physical ones, and step() / set_mask() take and return
+        # the logical box.  The extents depend on (ny, nz) alone: every rank picks the same.
+        self.nxl, self.lny, self.lnz = mask_local.shape
+        self.ny, self.nz = E.plane_dims(self.lny, self.lnz) if hasattr(E, 'plane_dims') else (self.lny, self.lnz)
+        self._padded = (self.ny, self.nz) != (self.lny, self.lnz)
         self.Lext = E.layout(self.nxl + 2, self.ny, self.nz)
         self.Lint = E.layout(self.nxl, self.ny, self.nz)
         assert self.Lint.sx == self.Lext.sx
@@ -522,6 +533,20 @@ class SlabStepper:
         self._gam = 0.0
         self.set_mask(mask_local)
 
+    def _pad(self, a, fill=0):
+        """host array over the caller's planes (n, lny, lnz) -> the slab's physical planes (n, ny, nz); scalars / None as they are"""
+        if not self._padded or a is None or np.isscalar(a):
+            return a
+        a = np.asarray(a)
+        assert a.shape[1:] == (self.lny, self.lnz), (a.shape, (self.lny, self.lnz))
+        out = np.full((a.shape[0], self.ny, self.nz), fill, dtype=a.dtype)
+        out[:, :self.lny, :self.lnz] = a
+        return out
+
+    def _logical(self, t):
+        """the caller's box of an internal (n, ny, nz) tensor (a view)"""
+        return t[:, :self.lny, :self.lnz] if self._padded else t
+
     @classmethod
     def from_local(cls, T0_local, mask_local, dx, mat, params, Tinf, **kw):
         """convenience for bench.py: stepper for this rank's slab (T0 only fixes nothing here; the field is
@@ -537,6 +562,8 @@ class SlabStepper:
         if hasattr(E, 'mask_epoch'):
             E.mask_epoch += 1                      # what the engine learnt about empty unit queues belongs to the old mask
             E._nofb.clear()
+        solid_logical = bool(np.asarray(mask_local).all())
+        mask_local = self._pad(np.asarray(mask_local).astype(np.bool_), False)
         m_ext = np.zeros((self.nxl + 2, self.ny, self.nz), dtype=np.bool_)
         m_ext[1:-1] = mask_local
         d_mask = L.to_layout(m_ext, torch.uint8)
@@ -548,17 +575,18 @@ class SlabStepper:
             d_mask[-1].copy_(hi)
         self.d_mask_ext = d_mask
         if hasattr(E, 'box_hint'):                 # all-solid on every rank -> the kernels' leaner build (a hint only)
-            f = E.vec(1); f.fill_(1.0 if bool(mask_local.all()) else 0.0)
+            f = E.vec(1); f.fill_(1.0 if solid_logical else 0.0)
             allf = E.vec(self.world)
             self.comm.all_gather(allf, f)
-            E.box_hint = 2 if float(allf.min()) >= 1.0 else 0
+            self._solid_everywhere = float(allf.min()) >= 1.0          # the caller's box, on every rank
+            E.box_hint = 2 if (self._solid_everywhere and not self._padded) else 0   # (the kernels' hint is about the physical box)
         self.flags_ext = E.build_flags(L, d_mask)
 
         def ext(a, fill):
             if a is None or np.isscalar(a):
                 return a
             e = np.full((self.nxl + 2, self.ny, self.nz), fill, dtype=np.asarray(a).dtype)
-            e[1:-1] = a
+            e[1:-1] = self._pad(a, fill)
             return e
         bc = self._bc
         neumann = None if bc['neumann'] is None else {f: ext(v, 0.0) for f, v in bc['neumann'].items()}
@@ -622,6 +650,7 @@ class SlabStepper:
         E.build_flags_planes(L, d_mask, self.flags_ext, k0, k1)
         E.build_packs_planes(L, d_mask, self.packs_ext, self.dx, self.mat, specs, k0, k1)
         E.box_hint = 0                 # a part that is still growing is not an all-solid box
+        self._solid_everywhere = False
 
     @property
     def stage_names(self):
@@ -695,7 +724,7 @@ class SlabStepper:
         buf = self._ext_bufs[self._cur]
         self._halo_ready = None                    # a foreign field: whatever halo was prefetched is not its halo
         src = t if isinstance(t, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(t), dtype=np.float64))
-        _interior(buf).copy_(src)
+        self._logical(_interior(buf)).copy_(src)
         return buf
 
     # -- how the axis-0 interface system is solved ------------------------------------------------------
@@ -776,7 +805,13 @@ class SlabStepper:
             # uniform lines need every cell of the slab in the mask: where the engine keeps the collective all-solid hint
             # (set_mask / set_mask_device) a slab that is not all-solid is not classified at all -- one kernel and one host
             # synchronisation less in every plan of a layer-birth loop
-            uniform = (getattr(E, 'box_hint', 2) == 2) and bool(E.lines_all_uniform(self.Lint, fl, pk[1]))
+            if self._padded:
+                # padded planes: the lines of the padding are off-mask, so the device classification would say "not uniform";
+                # but they are identity rows of a state that is zero there for good, their boundary planes are zero, their
+                # interface values and with them the correction come out as exact zeros -- what decides is the caller's box
+                uniform = bool(getattr(self, '_solid_everywhere', False)) and self._bc['dir_mask'] is None
+            else:
+                uniform = (getattr(E, 'box_hint', 2) == 2) and bool(E.lines_all_uniform(self.Lint, fl, pk[1]))
             if uniform:
                 dfr = E.deferred_setup(self.nxl, prm.theta, gam, self.DECAY_TOL)
         dflag = E.vec(3)
@@ -1214,6 +1249,7 @@ class SlabStepper:
             sw2(0, nl)
         mark()
         self._cur ^= 1
+        Oi = self._logical(Oi)
         if kind == 'numpy':
             return Oi.cpu().contiguous().numpy()
         if kind == 'torch':

@@ -236,8 +236,8 @@ def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, 
     dev_loop = on_device and st.device_births_supported()
     if dev_loop:
         E = st.engine
-        m_ext = np.zeros((i1 - i0 + 2, ny, nz), dtype=np.bool_)
-        m_ext[1:-1] = mask_full[i0:i1]
+        m_ext = np.zeros((i1 - i0 + 2, st.ny, st.nz), dtype=np.bool_)          # (the slab's planes may be padded: st._pad)
+        m_ext[1:-1] = st._pad(np.asarray(mask_full[i0:i1], dtype=np.bool_), False)
         d_full_int = st.Lext.to_layout(m_ext, torch.uint8)[1:-1]
         count = torch.zeros(1, dtype=torch.int64, device=E.device)
         plane_cells = np.asarray(mask_full).sum(axis=(0, 1)).astype(np.int64)
@@ -264,7 +264,7 @@ def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, 
             ks, ke = layers[next_birth]
             if dev_loop:
                 if not isinstance(T, torch.Tensor) or T.data_ptr() != dist_slab._interior(st._ext_bufs[st._cur]).data_ptr():
-                    T = dist_slab._interior(st._load_state(T))          # the state buffer itself (nothing stepped yet)
+                    T = st._logical(dist_slab._interior(st._load_state(T)))   # the state buffer itself (nothing stepped yet)
                 E.birth_planes(st.Lint, T, dist_slab._interior(st.d_mask_ext), d_full_int, ks, ke + 1, Ts, count)
                 fresh = ~plane_born[ks:ke + 1]
                 n_active += int(plane_cells[ks:ke + 1][fresh].sum())
@@ -290,7 +290,8 @@ def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, 
             advance(seg)
         t_now = te
         if on_frame is not None and any(abs(te - to) <= 1e-12 for to in times_out):
-            act = dist_slab._interior(st.d_mask_ext).cpu().contiguous().numpy().astype(bool) if dev_loop else mask_act[i0:i1].copy()
+            act = st._logical(dist_slab._interior(st.d_mask_ext)).cpu().contiguous().numpy().astype(bool) if dev_loop \
+                else mask_act[i0:i1].copy()
             on_frame(t_now, np.array(st.local_numpy(T)), act)
     return np.array(st.local_numpy(T)), nsteps
 

@@ -28,11 +28,14 @@ def _run_slabs(c, world, sizes, nsteps, opts=None, modes=None):
                 return a if (a is None or np.isscalar(a)) else np.asarray(a)[i0:i1]
             neumann = None if c['neumann'] is None else {f: loc(v) for f, v in c['neumann'].items()}
             robin_h = {f: loc(v) for f, v in c['robin_h'].items()} if isinstance(c['robin_h'], dict) else loc(c['robin_h'])
+            o = opts or {}
+            engine = dist_slab.HipEngine()
+            if o.get('no_pad'):                        # the caller's planes as they are (ragged lines on the GENERAL kernels)
+                engine.plane_dims = lambda ny, nz: (ny, nz)
             st = dist_slab.SlabStepper(c['mask'][i0:i1], c['dx'], hip.Material(**c['mat']),
                                        hip.Params(c['dt'], c['theta']), c['Tinf'], dir_mask=loc(c['dir_mask']),
                                        dir_value=loc(c['dir_value']), neumann=neumann, robin_h=robin_h,
-                                       comm=comms[rank])
-            o = opts or {}
+                                       comm=comms[rank], engine=engine)
             st._force_exact = bool(o.get('force_exact', False))
             st._allow_window = bool(o.get('allow_window', True))
             st._allow_fused = bool(o.get('allow_fused', True))
@@ -136,12 +139,17 @@ def test_slabs_interface_forms_agree(cfl, opts, mode):
     ((254, 16, 64), [64, 62, 64, 64], 3.0, dict(prefetch=True), 'deferred'),               # uneven slabs
     ((1024, 16, 32), [512, 512], 200.0, dict(prefetch=True), 'deferred'),                  # the bench's slab thickness and cfl
     ((1536, 16, 32), [512] * 3, 200.0, dict(prefetch=True), 'deferred'),                   # a middle rank: both corrections
-    ((192, 24, 40), [64] * 3, 1.0, dict(prefetch=True), 'deferred'),                       # nz not a multiple of 16: GENERAL kernels
-    ((128, 70, 16), [64, 64], 1.0, dict(prefetch=True), 'deferred'),                       # ragged axis-1 lines
+    ((192, 24, 40), [64] * 3, 1.0, dict(prefetch=True, no_pad=True), 'deferred'),          # nz not a multiple of 16: GENERAL kernels
+    ((128, 70, 16), [64, 64], 1.0, dict(prefetch=True, no_pad=True), 'deferred'),          # ragged axis-1 lines
+    ((192, 24, 40), [64] * 3, 1.0, dict(prefetch=True), 'deferred'),                       # the same on padded planes (the default): the
+    ((128, 70, 16), [64, 64], 1.0, dict(prefetch=True), 'deferred'),                       #   padding's lines get exact zero corrections
+    ((256, 70, 90), [64] * 4, 3.0, dict(prefetch=True), 'deferred'),                       # both plane extents padded
     ((256, 16, 64), [64] * 4, 3.0, dict(prefetch=True, allow_deferred=False), 'slab'),     # the two-pass form on the same grid
     ((256, 16, 64), [64] * 4, 300.0, dict(prefetch=True), 'deferred_exact'),               # nothing decays across 64 rows
     ((256, 16, 64), [64] * 4, 300.0, dict(prefetch=True, allow_fused=False), 'deferred_exact'),
-    ((192, 24, 40), [64] * 3, 2000.0, dict(prefetch=True), 'deferred_exact'),              # GENERAL axis-1 kernels, stiff
+    ((192, 24, 40), [64] * 3, 2000.0, dict(prefetch=True, no_pad=True), 'deferred_exact'), # GENERAL axis-1 kernels, stiff
+    ((192, 24, 40), [64] * 3, 2000.0, dict(prefetch=True), 'deferred_exact'),              # ... on padded planes
+    ((128, 70, 90), [64, 64], 200.0, dict(prefetch=True), 'deferred_exact'),               # both ranks with an end row, padded planes
     ((128, 16, 64), [64, 64], 200.0, dict(prefetch=True), 'deferred_exact'),               # two ranks, both with a global end row
     ((512, 16, 32), [64] * 8, 200.0, dict(prefetch=True), 'deferred_exact'),               # the strong-scaling shape: 8 x 64 planes
     ((254, 16, 64), [64, 62, 64, 64], 300.0, dict(prefetch=True), 'deferred_exact'),       # uneven thin slabs
@@ -291,3 +299,34 @@ def test_slab_step_over_real_rccl_self_loop():
             assert np.array_equal(outs[0][0], outs[1][0]), (cfl, opts, outs[0][1])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('shape,kind,world,opts', [((256, 70, 90), 'holes', 4, dict(prefetch=True)),
+                                                   ((192, 66, 250), 'solid', 3, dict(prefetch=True)),
+                                                   ((128, 100, 37), 'ellipsoid', 2, dict(prefetch=True, allow_fused=False)),
+                                                   ((256, 70, 90), 'solid', 4, dict(prefetch=True, force_exact=True))])
+def test_slabs_on_ragged_planes(shape, kind, world, opts):
+    """(ny, nz) that the kernels would not tile: the stepper pads the planes of every internal array (plane_dims), the ranks
+    exchange physical planes, the caller passes and gets the logical box; against the oracle on the logical grid"""
+    from oracle import adi_oracle as orc
+    from adi_thermal_fields_amd import dist_slab
+    from adi_thermal_fields_amd.dist_slab import split_planes
+    rng = np.random.default_rng(sum(shape) + world)
+    if kind == 'solid':
+        mask = np.ones(shape, bool)
+    elif kind == 'holes':
+        mask = rng.random(shape) > 0.1
+    else:
+        g = np.meshgrid(*[(np.arange(s) + 0.5) / s - 0.5 for s in shape], indexing='ij')
+        mask = (g[0] ** 2 + g[1] ** 2 + g[2] ** 2) <= 0.23
+    assert dist_slab.HipEngine().plane_dims(*shape[1:]) != shape[1:]
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask, T0=rng.uniform(20.0, 1500.0, shape),
+             dir_mask=None, dir_value=None, neumann={'y+': rng.uniform(0.0, 1e5, shape), 'z-': 2e4},
+             robin_h={'x-': 300.0, 'x+': 50.0, 'y-': rng.uniform(0.0, 500.0, shape), 'z+': 100.0}, Tinf=25.0, theta=0.5,
+             dt=3.0 * dx * dx / alpha, nsteps=2, births=None)
+    got = _run_slabs(c, world, split_planes(shape[0], world), 2, opts)
+    want = run_cart_case(orc, c)['T_final']
+    assert got.shape == shape and rel_linf(got, want) <= 1e-10, rel_linf(got, want)
+    assert np.array_equal(got[~mask], c['T0'][~mask])

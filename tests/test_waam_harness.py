@@ -387,3 +387,27 @@ def test_birth_kernel_and_incremental_packs_equal_the_full_rebuild():
         for a in range(3):
             assert np.array_equal(packs[a].coeff, ref_packs[a].coeff), (li, a)
             assert np.array_equal(packs[a].qflux, ref_packs[a].qflux), (li, a)
+
+
+@pytest.mark.gpu
+def test_layer_birth_on_a_ragged_grid_one_domain_and_slabs():
+    """a head of 72 x 66 x 50 voxels -- extents the kernels would not tile, so the single-domain grid runs on a padded
+    physical box (Layout) and the slabs on padded planes (SlabStepper.plane_dims): births in place on the padded device
+    mask, incremental flag / pack rebuilds, frames downloaded as the logical box; single domain against the oracle, 3
+    slabs against the single domain"""
+    from oracle import adi_oracle as orc
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from adi_thermal_fields_amd import dist_slab
+    waam, mask, layers, dx, times = _setup((72, 66, 50))
+    assert hip.Layout(*mask.shape).padded and dist_slab.HipEngine().plane_dims(66, 50) != (66, 50)
+    layers, times = layers[:8], times[:8]                                  # the first 16 planes: enough births, a quick oracle
+    outs = [0.0, times[-1]]
+    want, n1 = waam.run_layer_birth(orc, mask, dx, STEEL, 40.0, 20.0, 1000.0, 0.5, 2000.0, layers, times, outs)
+    frames = []
+    got, n2 = waam.run_layer_birth(hip, mask, dx, STEEL, 40.0, 20.0, 1000.0, 0.5, 2000.0, layers, times, outs,
+                                   on_frame=lambda t, T, m: frames.append((np.array(T), np.array(m))))
+    assert n1 == n2 and rel_linf(got, want) <= 1e-10, rel_linf(got, want)
+    assert all(T.shape == mask.shape and m.shape == mask.shape for T, m in frames)
+    assert np.array_equal(got[~mask], want[~mask])
+    slabs = _slab_run(3, [24, 24, 24], mask, dx, layers, times, outs)
+    assert slabs.shape == mask.shape and rel_linf(slabs, got) <= 1e-11, rel_linf(slabs, got)
