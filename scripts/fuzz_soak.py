@@ -23,7 +23,7 @@ for seed in range(S0, S0 + N):
     err = max(rel_linf(got[k], want[k]) for k in ('T_step1', 'T_final'))
     ok_off = np.array_equal(got['T_final'][~c['mask']], c['T0'][~c['mask']])
     worst = max(worst, err)
-    kinds[tag[:2]] = kinds.get(tag[:2], 0) + 1
+    k2 = (str(tag[0]), str(tag[1])); kinds[k2] = kinds.get(k2, 0) + 1
     if not (err <= 1e-10) or not ok_off:
         bad.append((seed, c['shape'], tag, err, ok_off))
     if (seed - S0) % 100 == 99:

@@ -22,7 +22,7 @@ for seed in range(S0, S0 + N):
     if rng.random() < 0.3:
         sizes[int(rng.integers(0, world))] += int(rng.choice([1, 3]))          # an odd slab: generic condensation kernels
     nx = sum(sizes)
-    ny = int(rng.choice([4, 8, 16, 24, 70])); nz = int(rng.choice([16, 32, 40, 64]))
+    ny = int(rng.choice([4, 8, 16, 24, 70, 100])); nz = int(rng.choice([16, 32, 40, 64, 50, 90]))     # (70, 100, 40, 50, 90: padded planes)
     shape = (nx, ny, nz)
     kind = str(rng.choice(['solid', 'solid', 'holes', 'ellipsoid']))
     if kind == 'solid':

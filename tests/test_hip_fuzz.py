@@ -5,7 +5,7 @@ and ragged tiles, padded segment counts), dense hand-built packs and sparse devi
 (Dirichlet and / or Neumann present), solid boxes, random holes, curved solids and thin walls, theta in {0.5, 1}.
 One-off soaks with the same generators (scripts/fuzz_soak.py): round 2's final build 3 400 Cartesian and 1 900 cylindrical cases,
 no failure, worst relative L-inf 7.2e-13 / 9.9e-13; round 3 (face constants, reciprocal-free surface runs, 16 rows from 160-row
-lines, 128-thread FAST workgroups, in-place cylindrical sweeps): see profiles/r03_fuzz_soak.txt."""
+lines, 128-thread FAST workgroups, in-place cylindrical sweeps, padded extents): see profiles/r03_fuzz_soak*.txt."""
 import numpy as np
 import pytest
 
@@ -16,7 +16,8 @@ STEEL = dict(rho=7800.0, cp=490.0, k=54.0)
 ALPHA = STEEL['k'] / (STEEL['rho'] * STEEL['cp'])
 
 # (long axis length, position of the long axis): the other two extents are drawn small so the oracle stays fast
-LONG = [64, 72, 96, 128, 136, 160, 192, 256, 264, 320, 384, 512, 520, 640]
+LONG = [64, 72, 96, 128, 136, 160, 192, 256, 264, 320, 384, 512, 520, 640,
+        100, 130, 250, 257, 300, 402]       # ragged lengths: these run on padded extents (Layout, adi_recommended_dims)
 
 
 def _case(seed):
@@ -27,7 +28,7 @@ def _case(seed):
     shape = [small(), small(), small()]
     shape[ax] = n_long
     if rng.random() < 0.5:                     # a second longish axis: tiles of the other strided sweep
-        shape[(ax + 1) % 3] = int(rng.choice([40, 64, 80]))
+        shape[(ax + 1) % 3] = int(rng.choice([40, 64, 80, 70, 100]))
     while shape[0] * shape[1] * shape[2] > 400000:
         i = int(np.argmin([s if j != ax else 1 << 30 for j, s in enumerate(shape)]))
         shape[(ax + 1) % 3] = max(3, shape[(ax + 1) % 3] // 2); shape[(ax + 2) % 3] = max(3, shape[(ax + 2) % 3] // 2)
