@@ -70,8 +70,10 @@ inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok,
                 if (n % m == 0 && (n / m == 16 || n / m == 32)) exact = m;
         // ... and for the fused explicit + sweep kernel, which holds at most 16 rows per thread, 10 / 12 / 14 rows where they cut
         // the line into exactly 16 or 32 segments (n = 160, 192, 224, 320, 384, 448; adi_sweep_strided_fx.hip, round 3)
-        if (fused && fused_exact && n >= 160 && !(n % 16 == 0 && ((n / 16) & (n / 16 - 1)) == 0))
-            for (int m = 10; m <= 14 && !exact; m += 2)
+        // (... and 9 / 11 / 13 / 15 rows: 144, 176, 208, 240 and 288, 352, 416, 480; adi_sweep_strided_fy.hip -- every multiple of 16
+        // up to 256 rows and of 32 up to 512 is an exact fit, which is what the padded extents round ragged lines up to)
+        if (fused && fused_exact && n >= 144 && !(n % 16 == 0 && ((n / 16) & (n / 16 - 1)) == 0))
+            for (int m = 9; m <= 15 && !exact; ++m)
                 if (n % m == 0 && (n / m == 16 || n / m == 32)) exact = m;
         if (exact) { mf = exact; lf = 16; }
         else if (wide_ok && n % 16 == 0 && (n / 16 == 8 || n / 16 == 16 || n / 16 == 32)) { mf = n / 16; lf = 32; }   // Lpf = 16

@@ -376,7 +376,8 @@ __device__ __forceinline__ bool fast_segment_load_fused(const double *__restrict
     // j-neighbour rows: a software pipeline D rows deep (they are L2 hits -- the tiles of the adjacent j-rows run next
     // door on the same XCD -- so a short pipeline covers their latency; a register pair per row in flight).  The
     // sched_barriers pin the order: without them the scheduler hoists every load to the top and spills.
-    constexpr int D = (M >= 8) ? (MIXED ? ADI_FUSE_D_MIXED : ADI_FUSE_D) : M;
+    constexpr int D0 = (M >= 8) ? (MIXED ? ADI_FUSE_D_MIXED : ADI_FUSE_D) : M;
+    constexpr int D = D0 < M ? D0 : M;                      // (9 rows per thread: nothing beyond the segment is prefetched)
     auto load_jm = [&](int r) -> double {
         return (r == 0) ? buf_load_f64(rT, vw - sy8, 0u) : buf_load_f64(rT, vb, R0 + (unsigned)r * st8 - sy8);
     };

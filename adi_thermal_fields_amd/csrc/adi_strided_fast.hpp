@@ -168,6 +168,9 @@ inline void launch_strided_fast(const StridedPlan &P, const double *in, const ui
 void strided_fast_fused_exact(int mf, bool has_q, const StridedPlan &P, const double *in, const uint8_t *flags,
                               const double *coeff, const double *qf, double *out, const LineGeom &g, const double *xlo,
                               const double *xhi, SweepScal s, unsigned *queue, hipStream_t st, const Fuse &fz);
+void strided_fast_fused_exact_odd(int mf, bool has_q, const StridedPlan &P, const double *in, const uint8_t *flags,
+                              const double *coeff, const double *qf, double *out, const LineGeom &g, const double *xlo,
+                              const double *xhi, SweepScal s, unsigned *queue, hipStream_t st, const Fuse &fz);   // 9 / 11 / 13 / 15 rows (adi_sweep_strided_fy.hip)
 
 // adi_sweep_strided_x.hip: launch_strided_fast<mf, ..., false> for mf = 20, 24, 28
 void strided_fast_exact(int mf, bool has_dir, bool has_q, const StridedPlan &P, const double *in, const uint8_t *flags,

@@ -201,6 +201,8 @@ static void launch_strided(const StridedPlan &P, const double *in, const uint8_t
             strided_fast_exact(P.Mf, HAS_DIR, HAS_Q, P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         else if (P.Mf == 10 || P.Mf == 12 || P.Mf == 14)  // exact fits of the fused kernel (no Dirichlet cells): adi_sweep_strided_fx.hip
             strided_fast_fused_exact(P.Mf, HAS_Q, P, in, flags, coeff, qf, out, g, xlo, xhi, s, queue, st, fz);
+        else if (P.Mf == 9 || P.Mf == 11 || P.Mf == 13 || P.Mf == 15)   // ... and the odd row counts: adi_sweep_strided_fy.hip
+            strided_fast_fused_exact_odd(P.Mf, HAS_Q, P, in, flags, coeff, qf, out, g, xlo, xhi, s, queue, st, fz);
         else if (P.Mf == 32) launch_strided_fast<32, HAS_DIR, HAS_Q, false>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         else if (P.Mf == 16) launch_strided_fast<16, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         else launch_strided_fast<8, HAS_DIR, HAS_Q, FUSE>(P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);

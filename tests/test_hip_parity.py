@@ -789,3 +789,39 @@ def test_exact_fit_row_counts(hip, n, ax):
                  nsteps=2, births=None)
         err = rel_linf(run_cart_case(hip, c)['T_final'], run_cart_case(orc, c)['T_final'])
         assert err <= TOL, (n, ax, kind, err)
+
+
+@pytest.mark.parametrize('n', [144, 176, 208, 240, 288, 352, 416, 480, 160, 224])
+def test_fused_exact_fit_row_counts(hip, n):
+    """the fused explicit + axis-0 kernel with 9 ... 15 rows per thread (adi_sweep_strided_fx.hip / _fy.hip): lines of every
+    multiple of 16 rows up to 256 and of 32 rows up to 512 cut into exactly 16 / 32 segments.  Solid blocks (lean build),
+    scalar faces with fluxes, voids, a curved solid (surface segments), per-voxel h -- against the oracle, and the fused
+    kernel against the two-kernel form of the same stages"""
+    from oracle import adi_oracle as orc
+    from adi_thermal_fields_amd import _lib
+    alpha = 54.0 / (7800.0 * 490.0)
+    shape = (n, 6, 64)
+    assert hip.recommended_dims(*shape) == shape                 # (an exact fit is not padded)
+    for kind in ('solid', 'solid_q', 'holes', 'ellipsoid', 'array_h'):
+        rng = np.random.default_rng(n + len(kind))
+        mask = np.ones(shape, bool)
+        if kind == 'holes':
+            mask = rng.random(shape) > 0.03
+        if kind == 'ellipsoid':
+            g = np.meshgrid(*[(np.arange(s) + 0.5) / s - 0.5 for s in shape], indexing='ij')
+            mask = (g[0] ** 2 + g[1] ** 2 + g[2] ** 2) <= 0.23
+        neu = {'x+': 1e5, 'x-': -2e4, 'y+': 3e4} if kind == 'solid_q' else None
+        rh = rng.uniform(0.0, 700.0, shape) if kind == 'array_h' else {'x-': 350.0, 'x+': 20.0, 'y-': 100.0, 'z+': 500.0}
+        dx = 1e-3
+        c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask, T0=rng.uniform(20.0, 1500.0, shape),
+                 dir_mask=None, dir_value=None, neumann=neu, robin_h=rh, Tinf=20.0, theta=0.5, dt=150.0 * dx * dx / alpha,
+                 nsteps=2, births=None)
+        err = rel_linf(run_cart_case(hip, c)['T_final'], run_cart_case(orc, c)['T_final'])
+        assert err <= TOL, (n, kind, err)
+        grid = hip.Grid3D(*shape, dx, mask)
+        mat = hip.Material(7800.0, 490.0, 54.0); prm = hip.Params(c['dt'], 0.5)
+        packs = hip.precompute_coeff_packs_unified(grid, mat, neumann=neu, robin_h=rh)
+        assert hip.fused_supported(grid)
+        U1 = hip.adi_explicit_sweep_axis0(c['T0'], grid, mat, prm, packs[0], Tinf=20.0)
+        U2 = hip.adi_sweep_axis(0, hip.adi_explicit_rhs(c['T0'], grid, mat, prm), grid, mat, prm, packs[0], Tinf=20.0)
+        assert rel_linf(U1, U2) <= 1e-13, (n, kind, rel_linf(U1, U2))
