@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libadi_hip.so')
 STAMP_SRC = 'adi_stamp.hip'
-SOURCES = ['adi_cart_api.hip', 'adi_explicit.hip', 'adi_sweep_contig.hip', 'adi_sweep_contig_x.hip', 'adi_sweep_strided.hip', 'adi_sweep_strided_x.hip', 'adi_sweep_strided_fc.hip', 'adi_sweep_strided_fx.hip', 'adi_sweep_strided_fy.hip', 'adi_condense.hip', 'adi_cyl.hip', 'adi_ctx.hip', 'adi_morph.hip', STAMP_SRC]
+SOURCES = ['adi_cart_api.hip', 'adi_explicit.hip', 'adi_sweep_contig.hip', 'adi_sweep_contig_x.hip', 'adi_sweep_strided.hip', 'adi_sweep_strided_x.hip', 'adi_sweep_strided_y.hip', 'adi_sweep_strided_fc.hip', 'adi_sweep_strided_fx.hip', 'adi_sweep_strided_fy.hip', 'adi_condense.hip', 'adi_cyl.hip', 'adi_ctx.hip', 'adi_morph.hip', STAMP_SRC]
 HEADERS = ['adi_core.hpp', 'adi_common.hpp', 'adi_cart_dev.hpp', 'adi_cart_host.hpp', 'adi_strided_dev.hpp', 'adi_strided_fast.hpp', 'adi_contig_dev.hpp', os.path.join('..', '..', 'include', 'adi_hip.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fno-fast-math', '-Wall',

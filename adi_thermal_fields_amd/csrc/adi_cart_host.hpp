@@ -65,8 +65,9 @@ inline StridedPlan strided_plan(const LineGeom &g, bool want_fast, bool wide_ok,
         // exact fits first: 20 / 24 / 28 rows per thread where they cut the line into exactly 16 or 32 segments (n = 320, 384,
         // 448, 640, 768, 896) -- with 16 or 32 rows those lines fill 20 - 28 of 32 segment slots of every workgroup
         int exact = 0;
-        if (!fused && !wide_ok && n >= 320 && !(n % 16 == 0 && ((n / 16) & (n / 16 - 1)) == 0))
-            for (int m = 20; m <= 28 && !exact; m += 4)
+        // (late round 3: 18 / 22 / 26 / 30 rows too -- 288, 352, 416, 480 and 576 ... 960 rows; adi_sweep_strided_y.hip)
+        if (!fused && !wide_ok && n >= 288 && !(n % 16 == 0 && ((n / 16) & (n / 16 - 1)) == 0))
+            for (int m = 18; m <= 30 && !exact; m += 2)
                 if (n % m == 0 && (n / m == 16 || n / m == 32)) exact = m;
         // ... and for the fused explicit + sweep kernel, which holds at most 16 rows per thread, 10 / 12 / 14 rows where they cut
         // the line into exactly 16 or 32 segments (n = 160, 192, 224, 320, 384, 448; adi_sweep_strided_fx.hip, round 3)

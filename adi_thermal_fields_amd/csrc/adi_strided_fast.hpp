@@ -177,5 +177,9 @@ void strided_fast_exact(int mf, bool has_dir, bool has_q, const StridedPlan &P, 
                         const double *coeff, const uint8_t *dmask, const double *dval, const double *qf, double *out,
                         const LineGeom &g, const double *xlo, const double *xhi, SweepScal s, unsigned *queue, hipStream_t st,
                         const Fuse &fz);
+void strided_fast_exact2(int mf, bool has_dir, bool has_q, const StridedPlan &P, const double *in, const uint8_t *flags,
+                        const double *coeff, const uint8_t *dmask, const double *dval, const double *qf, double *out,
+                        const LineGeom &g, const double *xlo, const double *xhi, SweepScal s, unsigned *queue, hipStream_t st,
+                        const Fuse &fz);   // 18 / 22 / 26 / 30 rows (adi_sweep_strided_y.hip)
 
 }  // namespace adi

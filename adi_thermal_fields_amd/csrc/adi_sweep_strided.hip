@@ -199,6 +199,8 @@ static void launch_strided(const StridedPlan &P, const double *in, const uint8_t
         else (void)hipMemsetAsync(queue, 0, sizeof(unsigned), st);
         if (P.Mf == 20 || P.Mf == 24 || P.Mf == 28)      // exact fits: instantiated in adi_sweep_strided_x.hip
             strided_fast_exact(P.Mf, HAS_DIR, HAS_Q, P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
+        else if (P.Mf == 18 || P.Mf == 22 || P.Mf == 26 || P.Mf == 30)   // ... and adi_sweep_strided_y.hip
+            strided_fast_exact2(P.Mf, HAS_DIR, HAS_Q, P, in, flags, coeff, dmask, dval, qf, out, g, xlo, xhi, s, queue, st, fz);
         else if (P.Mf == 10 || P.Mf == 12 || P.Mf == 14)  // exact fits of the fused kernel (no Dirichlet cells): adi_sweep_strided_fx.hip
             strided_fast_fused_exact(P.Mf, HAS_Q, P, in, flags, coeff, qf, out, g, xlo, xhi, s, queue, st, fz);
         else if (P.Mf == 9 || P.Mf == 11 || P.Mf == 13 || P.Mf == 15)   // ... and the odd row counts: adi_sweep_strided_fy.hip

@@ -756,11 +756,12 @@ def test_no_fallback_promise_is_learnt_per_configuration(hip):
     assert not all(v is True for p in pk2 for v in p._nofb.values())
 
 
-@pytest.mark.parametrize('n', [320, 384, 448, 640, 768, 896, 1280])
+@pytest.mark.parametrize('n', [320, 384, 448, 640, 768, 896, 1280, 288, 352, 416, 480, 576, 960])
 @pytest.mark.parametrize('ax', [0, 1, 2])
 def test_exact_fit_row_counts(hip, n, ax):
     """lines whose length is 20, 24 or 28 times a power of two: the FAST kernels take 20 / 24 / 28 rows per lane (thread) so
-    that the line fills the lanes of the interface solve exactly (adi_sweep_contig_x.hip, adi_sweep_strided_x.hip).  Solid
+    that the line fills the lanes of the interface solve exactly (adi_sweep_contig_x.hip, adi_sweep_strided_x.hip); the
+    strided ones also 18 / 22 / 26 / 30 rows (288 ... 480 and 576 ... 960 rows; adi_sweep_strided_y.hip).  Solid
     blocks, voids, a curved solid and the general pack, against the oracle.  n = 1280 is NOT an exact-fit case: lines
     beyond 1024 rows take the thread-per-line kernel (k_sweep_generic) on every axis; it is here as that path's test."""
     from oracle import adi_oracle as orc
