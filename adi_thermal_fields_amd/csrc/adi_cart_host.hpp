@@ -130,9 +130,8 @@ inline void fuse_tile_order(Fuse &fz, const StridedPlan &P, const Lay &L)
     fz.kt = 0; fz.ny = L.ny; fz.kg = 0;
     if (P.Mf != 0 && kg > 0 && L.nz % P.lines_f == 0) {
         const int kt = L.nz / P.lines_f;
-        int k2 = kg;
-        while (k2 > 1 && kt % k2 != 0) k2 >>= 1;
-        fz.kt = kt; fz.kg = k2;          // tiles_inner_f == ny * kt: the remap is a permutation of the tile ids
+        fz.kt = kt; fz.kg = kt < kg ? kt : kg;   // tiles_inner_f == ny * kt: the remap is a permutation of the tile ids (the
+                                                 // k-tiles beyond the last whole group form a narrower one, tile_jfast)
     }
 }
 
@@ -177,6 +176,9 @@ inline double line_fill(int axis, int n, int ny, int nz)
     if (axis == 2) {
         const int m = contig_fast_rows(n, contig_rows_per_lane(n));
         if (n % m != 0 || m < 8) return gen;
+        // (a segment count that is not a power of two also loses the coalesced loads -- solid 400^3 222 Gcell/s, 496^3 259
+        // against 355 - 365 at 448 / 512 rows -- but rating it 0.72 lower only traded cells for rate: 390^3 0.91 -> 0.97 ms,
+        // 490^3 1.65 -> 1.60, 450^3 1.44 -> 1.48; not kept)
         return (double)(n / m) / next_pow2(n / m);
     }
     if (nz % 16 != 0) return gen;                        // the strided FAST tiles are 16 whole lines wide
