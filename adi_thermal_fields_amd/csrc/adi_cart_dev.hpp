@@ -595,4 +595,90 @@ __device__ __forceinline__ void coal_store(double *__restrict__ gdst, double *st
     }
 }
 
+// The same for lines whose segment count S = n / M is not a power of two (Lp = next_pow2(S) lanes per line, the lanes beyond S
+// are padding): the lines of a wave are still consecutive in memory, n doubles each, so every half of the wave reads its
+// lines' contiguous range coalesced and scatters the pairs into the chunk slots of the lanes that own them.  (Until late round
+// 3 such lines took lane-owned 128-byte chunks: 496-row lines 259 Gcell/s against 365 at 512 rows.)
+template <int M>
+__device__ __forceinline__ void coal_half_range(int h, int n, int Lp, int &start, int &len, int &lph)
+{
+    lph = Lp <= 32 ? 32 / Lp : 0;                 // whole lines per half (0: one line spans both halves)
+    start = lph ? h * lph * n : h * 32 * M;       // first element of the half, from the wave base
+    len = lph ? lph * n : n - h * 32 * M;         // (Lp == 64 means n > 32 M: both halves own rows)
+    if (len > 32 * M) len = 32 * M;
+}
+
+template <int M>
+__device__ __forceinline__ int coal_slot(int e, int n, int Lp, int lph)
+{
+    constexpr int CH = M + 2;
+    const int ll = lph ? (int)(e >= n) + (int)(e >= 2 * n) + (int)(e >= 3 * n) : 0;     // line of the half (at most 4)
+    const int w = e - ll * n;
+    return (ll * Lp + w / M) * CH + w % M;
+}
+
+template <int M>
+__device__ __forceinline__ void coal_load_r(const double *__restrict__ gsrc /* wave base */, double *strip, int lane,
+                                            double (&d)[M], int n, int Lp)
+{
+    constexpr int CH = M + 2;
+    constexpr int NJ = (32 * M) / 128 > 0 ? (32 * M) / 128 : 1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int start, len, lph;
+        coal_half_range<M>(h, n, Lp, start, len, lph);
+        double2 v[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int e = 128 * j + 2 * lane;
+            v[j] = make_double2(0.0, 0.0);
+            if (e < len) v[j] = ld_stream2(reinterpret_cast<const double2 *>(gsrc + start + e));
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int e = 128 * j + 2 * lane;
+            if (e < len) *reinterpret_cast<double2 *>(strip + coal_slot<M>(e, n, Lp, lph)) = v[j];
+        }
+        wave_lds_fence();
+        if ((lane >> 5) == h) {
+            const double *c = strip + (lane & 31) * CH;
+#pragma unroll
+            for (int i = 0; i < M / 2; ++i) {
+                const double2 t = *reinterpret_cast<const double2 *>(c + 2 * i);
+                d[2 * i] = t.x;
+                d[2 * i + 1] = t.y;
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void coal_store_r(double *__restrict__ gdst, double *strip, int lane, const double (&d)[M], int n,
+                                             int Lp, bool owns, bool nt)
+{
+    constexpr int CH = M + 2;
+    constexpr int NJ = (32 * M) / 128 > 0 ? (32 * M) / 128 : 1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int start, len, lph;
+        coal_half_range<M>(h, n, Lp, start, len, lph);
+        if ((lane >> 5) == h && owns) {            // (padding lanes own no rows: their chunk slots are never read below)
+            double *c = strip + (lane & 31) * CH;
+#pragma unroll
+            for (int i = 0; i < M / 2; ++i) *reinterpret_cast<double2 *>(c + 2 * i) = make_double2(d[2 * i], d[2 * i + 1]);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int e = 128 * j + 2 * lane;
+            if (e < len) {
+                const double2 t = *reinterpret_cast<const double2 *>(strip + coal_slot<M>(e, n, Lp, lph));
+                st_stream2(reinterpret_cast<double2 *>(gdst + start + e), t, nt);
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
 }  // namespace adi

@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     const long base = (long)pi * L.sx + (long)(line - pi * (unsigned)L.ny) * n + r0;
 
     constexpr bool VEC = MODE != 0;
-    __shared__ __align__(16) double strips[MODE == 2 ? 4 * 32 * (M + 2) : 2];
-    double *strip = strips + (MODE == 2 ? wave * 32 * (M + 2) : 0);
+    __shared__ __align__(16) double strips[MODE >= 2 ? 4 * 32 * (M + 2) : 2];
+    double *strip = strips + (MODE >= 2 ? wave * 32 * (M + 2) : 0);
     // MODE 2: the 64/Lp lines of a unit are consecutive in memory (host checks ny % lw == 0), so the wave's 64*M
     // doubles start at the base of lane 0
     const long wbase = __shfl(base, 0);
@@ -111,7 +111,13 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     load_bytes_contig<M, VEC>(flags, base, r0, n, active, fb);
     if (HAS_DIR) load_bytes_contig<M, VEC>(dmask, base, r0, n, active, db);
     if constexpr (MODE == 2) coal_load<M>(in + wbase, strip, lane, d);
-    else load_rows_contig<M, VEC>(in, base, r0, n, active, d);
+    else if constexpr (MODE == 3) {
+        coal_load_r<M>(in + wbase, strip, lane, d, n, Lp);          // segment count not a power of two: lanes beyond it are padding
+        if (r0 >= n) {
+#pragma unroll
+            for (int r = 0; r < M; ++r) d[r] = 0.0;
+        }
+    } else load_rows_contig<M, VEC>(in, base, r0, n, active, d);
     // the two ends of a line are always exposed: fetch their coefficient / flux with the first batch of loads
     const bool sp0 = active && li == 0, spS = active && (r0 + M == n);
     // (per-face scalars, SweepScal::fconst: nothing is loaded, the values follow from the flags below)
@@ -183,6 +189,8 @@ __global__ __launch_bounds__(256) void k_sweep_contig_fast(
     else if (kind >= SEG_TAIL) mixed_lane_back_solve<M>(kind, Lm, U, bmod, a0, d, xL, xS);
     if constexpr (MODE == 2) {
         coal_store<M>(out + wbase, strip, lane, d, s.nt != 0);      // (the host takes this mode only when no lane is padding)
+    } else if constexpr (MODE == 3) {
+        coal_store_r<M>(out + wbase, strip, lane, d, n, Lp, !pad, s.nt != 0);
     } else if (pad) {
         // nothing to store
     } else if (VEC) {
@@ -208,10 +216,22 @@ inline void launch_contig_fast(const double *in, const uint8_t *flags, const dou
     // coalesced + LDS-transposed access: whole units of contiguous lines (full last unit, no plane straddling)
     const bool coal = vec && MF >= 4 && Lpf * MF == L.nz && (L.ny % lwf == 0) &&
                       (((long)L.nx * L.ny) % lwf == 0);
+    // ... and the same access for segment counts that are not a power of two (16 rows per lane: 272 ... 496-row lines, the
+    // lengths padded extents often end on): whole units of whole lines, lanes beyond the last segment are padding
+    // Only with the caller's all-solid hint (SweepScal::box): where every line ends in a surface segment -- a padded nz -- the
+    // kernel is bound by the serial work of those lanes, not by its loads, and the extra index arithmetic of this mode costs
+    // more than the coalescing gains (256 x 256 x 257 on a 272-row box: 170 Gcell/s with lane-owned chunks, 148 with this mode;
+    // solid 256 x 256 x 496: 227 -> 283).
+    const bool coal_r = s.box != 0 && vec && MF == 16 && L.nz % MF == 0 && Lpf * MF != L.nz && (L.ny % lwf == 0) &&
+                        (((long)L.nx * L.ny) % lwf == 0);
     if (coal)
         hipLaunchKernelGGL((k_sweep_contig_fast<(MF >= 4 ? MF : 4), 2, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
                            dmask, dval, qf, out, L, Lpf, s, nunits_f, queue, make_unic<(MF >= 4 ? MF : 4)>(s.tg));
-    else if (vec)
+    else if (coal_r) {
+        if constexpr (MF == 16)
+            hipLaunchKernelGGL((k_sweep_contig_fast<16, 3, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
+                               dmask, dval, qf, out, L, Lpf, s, nunits_f, queue, U);
+    } else if (vec)
         hipLaunchKernelGGL((k_sweep_contig_fast<MF, 1, HAS_DIR, HAS_Q>), dim3(grid), dim3(256), 0, st, in, flags, coeff,
                            dmask, dval, qf, out, L, Lpf, s, nunits_f, queue, U);
     else
