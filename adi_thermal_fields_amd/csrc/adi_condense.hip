@@ -490,6 +490,32 @@ __global__ __launch_bounds__(256) void k_interface_deferred(const double *__rest
     uhi[l] = hi;
 }
 
+// The same for lines that are NOT uniform (curved solids, voids, Dirichlet cells): every line has its own decaying
+// homogeneous solutions, computed once per plan by two ordinary axis-0 sweeps with zero right-hand sides and unit boundary
+// values.  om_*: their value in the plane next to the interface -- om_lo_own / om_hi_own of this rank's lines, om_hi_prev /
+// om_lo_next received from the neighbours at plan time.  Per line and boundary a 2 x 2 system, as above with two weights.
+__global__ __launch_bounds__(256) void k_interface_deferred_lines(
+    const double *__restrict__ first, const double *__restrict__ last, const double *__restrict__ prev_last,
+    const double *__restrict__ next_first, const double *__restrict__ om_lo_own, const double *__restrict__ om_hi_prev,
+    const double *__restrict__ om_hi_own, const double *__restrict__ om_lo_next, long nlines, double *__restrict__ ulo,
+    double *__restrict__ uhi)
+{
+    const long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlines) return;
+    double lo = 0.0, hi = 0.0;
+    if (prev_last != nullptr) {
+        const double gL = prev_last[l], wl = om_lo_own[l], wh = om_hi_prev[l];
+        const double F = __builtin_fma(wl, gL, first[l]) / (1.0 - wl * wh);     // this rank's first unknown
+        lo = __builtin_fma(wh, F, gL);                                          // the neighbour's last one: what w_lo multiplies
+    }
+    if (next_first != nullptr) {
+        const double wh = om_hi_own[l], wl = om_lo_next[l];
+        hi = __builtin_fma(wl, last[l], next_first[l]) / (1.0 - wl * wh);       // the neighbour's first unknown
+    }
+    ulo[l] = lo;
+    uhi[l] = hi;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5d: the deferred form WITHOUT decay (thin slabs, strong scaling).  x = x0 + xlo * psi_lo + xhi * psi_hi still holds;
 // what changes is that (1) the interface system couples all ranks -- the all-gather + k_interface of the `exact` form, fed
@@ -615,6 +641,21 @@ int adi_interface_deferred(const double *d_first, const double *d_last, const do
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }
+int adi_interface_deferred_lines(const double *d_first, const double *d_last, const double *d_prev_last,
+                                 const double *d_next_first, const double *d_om_lo_own, const double *d_om_hi_prev,
+                                 const double *d_om_hi_own, const double *d_om_lo_next, long nlines, double *d_ulo,
+                                 double *d_uhi, void *stream)
+{
+    ADI_REQUIRE(d_first && d_last && d_ulo && d_uhi && nlines > 0, "adi_interface_deferred_lines: bad argument");
+    ADI_REQUIRE(!d_prev_last || (d_om_lo_own && d_om_hi_prev), "adi_interface_deferred_lines: lower boundary without its weights");
+    ADI_REQUIRE(!d_next_first || (d_om_hi_own && d_om_lo_next), "adi_interface_deferred_lines: upper boundary without its weights");
+    hipLaunchKernelGGL(k_interface_deferred_lines, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       d_first, d_last, d_prev_last, d_next_first, d_om_lo_own, d_om_hi_prev, d_om_hi_own, d_om_lo_next,
+                       nlines, d_ulo, d_uhi);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
 int adi_deferred_exact_setup(const uint8_t *d_flags_first, const uint8_t *d_flags_last, const double *d_coeff_first,
                              const double *d_coeff_last, double theta, double gam, double dt, double w0, double wn,
                              long nlines, double *d_mat, double *d_kap, void *stream)

@@ -411,16 +411,48 @@ class HipEngine:
         self.check(self.lib.adi_interface_deferred(h._p(first), h._p(last), h._p(prev_last), h._p(next_first), omega,
                                                    nlines, h._p(ulo), h._p(uhi), self._sp()))
 
-    def sweep_corrected(self, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, ulo, uhi, w_corr):
-        """axis-1 sweep of t_in + w[i] * ulo + w[n-1-i] * uhi"""
+    def sweep_corrected(self, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, ulo, uhi, w_corr, wlo=None, whi=None):
+        """axis-1 sweep of t_in + w[i] * ulo + w[n-1-i] * uhi; with wlo / whi ((K, ny, nz) dense, the planes of whi counted
+        from the far end) the weights are per cell and w says which planes have them"""
         h = self.hip
         w = self._workspace(Li)
         key, bit = self._promise('sweep', 1, variant, Li, flags, pack)
         a = list(self._args(1, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf))
         a[12] |= bit
-        self.check(self.lib.adi_sweep_corrected(*a[1:], h._p(t_out), h._p(ulo), h._p(uhi), h._p(w_corr), self._fc(pack),
-                                                h._p(w), w.numel(), self._sp()))
+        wp = wlo if wlo is not None else whi
+        ps, npl = (int(wp.stride(0)), int(wp.shape[0])) if wp is not None else (0, 0)
+        assert wlo is None or whi is None or (wlo.stride(0) == whi.stride(0) and wlo.shape[0] == whi.shape[0])
+        self.check(self.lib.adi_sweep_corrected(*a[1:], h._p(t_out), h._p(ulo), h._p(uhi), h._p(w_corr), h._p(wlo), h._p(whi),
+                                                ps, npl, self._fc(pack), h._p(w), w.numel(), self._sp()))
         self._learn(key, w)
+
+    # the deferred form for lines that are not uniform (ABI v17): per-line homogeneous solutions
+    def homogeneous_solution(self, variant, Li, flags, pack, theta, gam, dt, lower):
+        """w_lo (lower=True: unit value of the unknown below the slab) or w_hi of every sharded-axis line: the ordinary axis-0
+        sweep of a zero field with Tinf = 0, no fluxes, zero Dirichlet values and d_xlo (d_xhi) = 1 -> (nx, ny, nz) tensor"""
+        from . import _lib
+        nl = Li.ny * Li.nz
+        has_dir = variant in (_lib.SWEEP_GENERAL, _lib.SWEEP_NO_Q)
+        v = _lib.SWEEP_NO_Q if has_dir else _lib.SWEEP_LEAN
+        zero = Li.empty(zero=True)
+        one = torch.ones(nl, dtype=torch.float64, device=self.device)
+        pk = (pack[0], pack[1], (Li.empty(zero=True) if has_dir else None), None)
+        out = Li.empty()
+        # (dense reads, no face constants: the coefficient arrays as they are; a one-off per plan)
+        h = self.hip
+        w = self._workspace(Li)
+        a = list(self._args(0, v, Li, zero, flags, pk, theta, gam, dt, 0.0))
+        a[12] = 0
+        self.check(self.lib.adi_sweep(*a, h._p(out), h._p(one if lower else None), h._p(None if lower else one), None,
+                                      h._p(w), w.numel(), self._sp()))
+        return out
+
+    def interface_deferred_lines(self, first, last, prev_last, next_first, om, nlines, ulo, uhi):
+        h = self.hip
+        self.check(self.lib.adi_interface_deferred_lines(h._p(first), h._p(last), h._p(prev_last), h._p(next_first),
+                                                         h._p(om.get('lo_own')), h._p(om.get('hi_prev')), h._p(om.get('hi_own')),
+                                                         h._p(om.get('lo_next')), nlines, h._p(ulo), h._p(uhi), self._sp()))
+
 
     def condense0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, cond, r0_out=None):
         """r0_out (optional, a view of the box in an array laid out like T_ext): also receives R0"""
@@ -527,6 +559,7 @@ class SlabStepper:
         self._allow_dots = True                    # False: pass A as its own kernel (reads the slab a second time)
         self._allow_deferred = True                # False: never the deferred form (zero-boundary solve + correction on load)
         self._allow_deferred_exact = True          # False: thin slabs (no decay) keep the two-pass all-gather form
+        self._allow_deferred_lines = True          # False: lines that are not uniform keep the two-pass forms
         self._send_g_only = True                   # False: every step exchanges the matrix parts of the interface too
         self._comm_stream, self._use_streams = None, False
         self._halo_ready, self._halo_event = None, None
@@ -844,6 +877,15 @@ class SlabStepper:
                 self._a0_key, self._a0 = key, plan
                 self.axis0_mode = plan['mode']
                 return plan
+        # Lines that are not uniform (curved solids, voids, Dirichlet cells): the same algebra with the two homogeneous solutions
+        # of EVERY line, where they have decayed across every slab ('deferred_lines', include/adi_hip.h ABI v17).  Collective.
+        if (self._allow_deferred and self._allow_deferred_lines and hasattr(E, 'homogeneous_solution') and not self._force_exact
+                and self.nxl >= 2 and prm.theta * gam > 0.0):
+            plan = self._plan_deferred_lines(fl, pk, gam, bool(float(alld[:, 1].min()) >= 1.0))
+            if plan is not None:
+                self._a0_key, self._a0 = key, plan
+                self.axis0_mode = plan['mode']
+                return plan
         K = self._window_guess(gam)
         cand = {}
         if not self._force_exact:
@@ -926,6 +968,45 @@ class SlabStepper:
         self._a0_key, self._a0 = key, plan
         self.axis0_mode = plan['mode']
         return plan
+
+    def _plan_deferred_lines(self, fl, pk, gam, fused_ok):
+        """plan of the deferred form with per-line homogeneous solutions, or None (not decayed on some rank).  Per rank and
+        plan: two axis-0 sweeps of a zero field with unit boundary values -> w_lo, w_hi of every line; K planes of each are
+        kept (beyond them every entry must be below DECAY_TOL, checked on the device), the planes next to the interfaces
+        travel to the neighbours once."""
+        E, prm, n, nl_ = self.engine, self.params, self.nxl, self.nlines
+        first, last = self.rank == 0, self.rank == self.world - 1
+        # where to look: the reach of the uniform row's solution plus a margin (a run that ends in a line start reflects);
+        # what decides is the check below
+        K = min(n, int(E.deferred_setup(n, prm.theta, gam, self.DECAY_TOL)['reach']) + 8)
+        ok = K < n
+        om, Wlo, Whi = {}, None, None
+        if ok and not first:
+            W = E.homogeneous_solution(self.variant, self.Lint, fl, pk, prm.theta, gam, prm.dt, True)
+            ok = bool(float(W[K:].abs().max()) <= self.DECAY_TOL)             # NaN compares false
+            Wlo = W[:K].contiguous()
+            om['lo_own'] = W[0].clone()
+        if ok and not last:
+            W = E.homogeneous_solution(self.variant, self.Lint, fl, pk, prm.theta, gam, prm.dt, False)
+            ok = bool(float(W[:n - K].abs().max()) <= self.DECAY_TOL)
+            Whi = W[n - K:].flip(0).contiguous()                              # plane q belongs to slab plane n-1-q
+            om['hi_own'] = W[n - 1].clone()
+        flag, allf = E.vec(1), E.vec(self.world)
+        flag.fill_(1.0 if ok else 0.0)
+        self.comm.all_gather(allf, flag)
+        if float(allf.min()) < 1.0:
+            return None
+        # the planes next to the interfaces, once per plan: mine down / up, the neighbours' back
+        dummy = E.vec(nl_).view(self.ny, self.nz)
+        om['hi_prev'] = None if first else E.vec(nl_).view(self.ny, self.nz)
+        om['lo_next'] = None if last else E.vec(nl_).view(self.ny, self.nz)
+        self.comm.exchange_planes(om.get('lo_own', dummy), om.get('hi_own', dummy),
+                                  dummy if first else om['hi_prev'], dummy if last else om['lo_next'])
+        w01 = E.vec(n)                     # (vec() is uninitialised memory on the product engine)
+        w01.zero_()
+        w01[:K] = 1.0
+        return dict(mode='deferred_lines', K=K, fused=fused_ok, dots=False, keep_r0=False, chunks=[], om=om, Wlo=Wlo, Whi=Whi,
+                    w01=w01, ulo=E.vec(nl_), uhi=E.vec(nl_), prev_last=E.vec(nl_), next_first=E.vec(nl_))
 
     def _condense_box(self, plan, L, src, p0, p1, j0, j1, cond):
         """pass A on planes [p0, p1), rows [j0, j1) of the slab.  src: the explicit stage's output (interior view) or,
@@ -1152,9 +1233,15 @@ class SlabStepper:
                 self.comm.exchange_planes(Bi[0], Bi[nl - 1], plan['prev_last'].view(self.ny, self.nz),
                                           plan['next_first'].view(self.ny, self.nz))
                 first, last = self.rank == 0, self.rank == self.world - 1
-                E.interface_deferred(Bi[0], Bi[nl - 1], None if first else plan['prev_last'],
-                                     None if last else plan['next_first'], plan['dfr']['omega'], self.nlines, plan['ulo'],
-                                     plan['uhi'])
+                if plan['mode'] == 'deferred_lines':
+                    # per-line weights (the axis-1 sweep reads them per cell on the K planes at each end)
+                    E.interface_deferred_lines(Bi[0], Bi[nl - 1], None if first else plan['prev_last'],
+                                               None if last else plan['next_first'], plan['om'], self.nlines, plan['ulo'],
+                                               plan['uhi'])
+                else:
+                    E.interface_deferred(Bi[0], Bi[nl - 1], None if first else plan['prev_last'],
+                                         None if last else plan['next_first'], plan['dfr']['omega'], self.nlines, plan['ulo'],
+                                         plan['uhi'])
         elif fused:
             # R0 never reaches HBM: both passes of the axis-0 sweep evaluate it from the state (halo planes included,
             # so they must have landed; in an nsub loop they were sent while the previous step's last sweep ran)
@@ -1218,7 +1305,11 @@ class SlabStepper:
             ev_x = self._axis0_pipeline(plan, Ai, Bi)
             self._axis0_finish(plan, Ai, Bi, ev_x)
         # 4. local sweeps
-        if plan is not None and plan['mode'].startswith('deferred'):
+        if plan is not None and plan['mode'] == 'deferred_lines':
+            E.sweep_corrected(v, Li, Bi, fl, self.packs_int[1], prm.theta, gam, prm.dt, self.Tinf, Ai,
+                              None if self.rank == 0 else plan['ulo'], None if self.rank == self.world - 1 else plan['uhi'],
+                              plan['w01'], plan['Wlo'], plan['Whi'])
+        elif plan is not None and plan['mode'].startswith('deferred'):
             ex_ = plan['mode'] == 'deferred_exact'        # (there the end ranks carry a Sherman-Morrison term on both vectors)
             E.sweep_corrected(v, Li, Bi, fl, self.packs_int[1], prm.theta, gam, prm.dt, self.Tinf, Ai,
                               None if (self.rank == 0 and not ex_) else plan['ulo'],

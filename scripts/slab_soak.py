@@ -41,7 +41,8 @@ for seed in range(S0, S0 + N):
              dir_mask=None, dir_value=None, neumann=neumann, robin_h=robin_h, Tinf=20.0, theta=float(rng.choice([0.5, 1.0])),
              dt=cfl * dx * dx / alpha, nsteps=3, births=None)
     opts = dict(prefetch=bool(rng.random() < 0.7), allow_fused=bool(rng.random() < 0.8), allow_dots=bool(rng.random() < 0.7),
-                allow_deferred=bool(rng.random() < 0.85), allow_deferred_exact=bool(rng.random() < 0.8))
+                allow_deferred=bool(rng.random() < 0.85), allow_deferred_exact=bool(rng.random() < 0.8),
+                allow_deferred_lines=bool(rng.random() < 0.6))
     modes = set()
     got = D._run_slabs(c, world, sizes, 3, opts, modes)
     want = run_cart_case(hip, c)['T_final']

@@ -219,14 +219,47 @@ class CpuEngine:
         assert np.abs(B @ sol - t.T).max() <= 1e-9 * max(1.0, np.abs(t).max())           # the two-vector form is exact
         clo.numpy()[:] = sol[0]; chi.numpy()[:] = sol[1]
 
-    def sweep_corrected(self, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, ulo, uhi, w_corr):
+    def sweep_corrected(self, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, ulo, uhi, w_corr, wlo=None, whi=None):
         w = w_corr.numpy()
         x = t_in.numpy().copy()
+        n = Li.nx
         if ulo is not None:
-            x += w[:, None, None] * ulo.numpy().reshape(1, Li.ny, Li.nz)
+            u = ulo.numpy().reshape(1, Li.ny, Li.nz)
+            if wlo is not None:                # per-cell weights on the planes where w says so
+                K = wlo.shape[0]
+                x[:K] += w[:K, None, None] * wlo.numpy() * u
+            else:
+                x += w[:, None, None] * u
         if uhi is not None:
-            x += w[::-1][:, None, None] * uhi.numpy().reshape(1, Li.ny, Li.nz)
+            u = uhi.numpy().reshape(1, Li.ny, Li.nz)
+            if whi is not None:                # plane q of whi belongs to slab plane n-1-q
+                K = whi.shape[0]
+                x[n - K:] += (w[:K, None, None] * whi.numpy())[::-1] * u
+            else:
+                x += w[::-1][:, None, None] * u
         self.sweep(1, variant, Li, torch.from_numpy(x), flags, pack, theta, gam, dt, Tinf, t_out)
+
+    # the deferred form with per-line homogeneous solutions (include/adi_hip.h, ABI v17), restated with dense solves
+    def homogeneous_solution(self, variant, Li, flags, pack, theta, gam, dt, lower):
+        z = torch.zeros(Li.nx, Li.ny, Li.nz, dtype=torch.float64)
+        out = torch.empty_like(z)
+        one = torch.ones(Li.ny * Li.nz, dtype=torch.float64)
+        self.sweep(0, variant, Li, z, flags, (pack[0], pack[1], None, None), theta, gam, dt, 0.0, out,
+                   xlo=one if lower else None, xhi=None if lower else one)
+        return out
+
+    def interface_deferred_lines(self, first, last, prev_last, next_first, om, nlines, ulo, uhi):
+        f, l = first.numpy().reshape(-1), last.numpy().reshape(-1)
+        lo = np.zeros(nlines); hi = np.zeros(nlines)
+        if prev_last is not None:
+            gL = prev_last.numpy().reshape(-1)
+            wl, wh = om['lo_own'].numpy().reshape(-1), om['hi_prev'].numpy().reshape(-1)
+            F = (f + wl * gL) / (1.0 - wl * wh)
+            lo = gL + wh * F
+        if next_first is not None:
+            wh, wl = om['hi_own'].numpy().reshape(-1), om['lo_next'].numpy().reshape(-1)
+            hi = (next_first.numpy().reshape(-1) + wl * l) / (1.0 - wl * wh)
+        ulo.copy_(torch.from_numpy(lo)); uhi.copy_(torch.from_numpy(hi))
 
     def sweep(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, xlo=None, xhi=None):
         a, b, c, d = _line_systems(axis, t_in, flags, pack, theta, gam, dt, Tinf)

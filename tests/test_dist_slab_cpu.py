@@ -98,6 +98,8 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q, opts=None):
         st._allow_dots = bool(opts.get('allow_dots', True))
         st._allow_deferred = bool(opts.get('allow_deferred', True))
         st._allow_deferred_exact = bool(opts.get('allow_deferred_exact', True))
+        # (off unless a test asks for it: the cases below were written for the two-pass forms it would otherwise replace)
+        st._allow_deferred_lines = bool(opts.get('allow_deferred_lines', False))
         T = torch.from_numpy(np.ascontiguousarray(c['T0'][i0:i1]))
         for s in range(nsteps):
             T = st.step(T, prefetch_halo=bool(opts.get('prefetch', False)) and s + 1 < nsteps)
@@ -299,3 +301,34 @@ def test_padded_planes_match_single_domain(world, name, sizes, opts):
     want = run_cart_case(orc, c)['T_final']
     assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
     assert np.array_equal(got[~c['mask']], c['T0'][~c['mask']])
+
+
+@pytest.mark.parametrize('world,name,sizes,opts', [
+    (2, 'decay:128', [64, 64], dict(prefetch=True)),                               # holes, per-voxel arrays: thick slabs
+    (3, 'decay:192', [64] * 3, dict(prefetch=True, allow_fused=False)),            # a middle rank: both corrections
+    (4, 'decay:254', [64, 62, 64, 64], dict(prefetch=True)),                       # uneven slabs
+    (4, 'decay:256', [64] * 4, dict(prefetch=True, pad=(2, 3))),                   # ... on padded planes
+])
+def test_deferred_form_with_per_line_solutions_matches_single_domain(world, name, sizes, opts):
+    """lines that are not uniform: zero-boundary solve + one plane to each neighbour + 2 x 2 systems with per-line weights +
+    correction planes added by the axis-1 sweep's loads ('deferred_lines'); reference engine with dense solves"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import adi_oracle as orc
+    from helpers import run_cart_case, rel_linf
+    c = _case(name)
+    got, modes = _run_world(world, name, sizes, c['nsteps'], dict(opts, allow_deferred_lines=True))
+    assert modes == {'deferred_lines'}, modes
+    want = run_cart_case(orc, c)['T_final']
+    assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
+    assert np.array_equal(got[~c['mask']], c['T0'][~c['mask']])
+
+
+def test_deferred_form_with_per_line_solutions_declines_without_decay():
+    """stiff step, thin slabs: the homogeneous solutions do not decay across 16 planes -> the all-gather form as before"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import adi_oracle as orc
+    from helpers import run_cart_case, rel_linf
+    c = _case('stiff:64')
+    got, modes = _run_world(4, 'stiff:64', [16] * 4, c['nsteps'], dict(prefetch=True, allow_deferred_lines=True))
+    assert modes == {'exact'}, modes
+    assert rel_linf(got, run_cart_case(orc, c)['T_final']) <= 1e-12

@@ -43,6 +43,8 @@ def _run_slabs(c, world, sizes, nsteps, opts=None, modes=None):
             st._keep_r0 = bool(o.get('keep_r0', True))
             st._allow_deferred = bool(o.get('allow_deferred', True))
             st._allow_deferred_exact = bool(o.get('allow_deferred_exact', True))
+            # (off unless a test asks for it: most cases here were written for the two-pass forms it would otherwise replace)
+            st._allow_deferred_lines = bool(o.get('allow_deferred_lines', False))
             if 'dots_max' in o:
                 st.DOTS_MAX_NONUNIFORM = o['dots_max']
             T = hip.to_device(np.ascontiguousarray(c['T0'][i0:i1]))
@@ -329,4 +331,45 @@ def test_slabs_on_ragged_planes(shape, kind, world, opts):
     got = _run_slabs(c, world, split_planes(shape[0], world), 2, opts)
     want = run_cart_case(orc, c)['T_final']
     assert got.shape == shape and rel_linf(got, want) <= 1e-10, rel_linf(got, want)
+    assert np.array_equal(got[~mask], c['T0'][~mask])
+
+
+@pytest.mark.parametrize('shape,kind,sizes,cfl,opts', [
+    ((256, 16, 64), 'holes', [64] * 4, 3.0, dict(prefetch=True)),                              # FAST kernels, voids in every line
+    ((256, 16, 64), 'holes', [64] * 4, 3.0, dict(prefetch=True, allow_fused=False)),
+    ((256, 48, 64), 'ellipsoid', [64] * 4, 3.0, dict(prefetch=True)),                          # a curved solid across all slabs
+    ((254, 16, 64), 'dirichlet', [64, 62, 64, 64], 3.0, dict(prefetch=True)),                  # Dirichlet cells, uneven slabs
+    ((1024, 16, 32), 'ellipsoid', [512, 512], 200.0, dict(prefetch=True)),                     # the bench's slab thickness and cfl
+    ((192, 70, 90), 'ellipsoid', [64] * 3, 1.0, dict(prefetch=True)),                          # padded planes
+    ((192, 24, 40), 'holes', [64] * 3, 1.0, dict(prefetch=True, no_pad=True)),                 # GENERAL axis-1 kernels
+])
+def test_slabs_deferred_form_with_per_line_solutions(shape, kind, sizes, cfl, opts):
+    """lines that are not uniform ('deferred_lines', ABI v17): per-line homogeneous solutions from two axis-0 sweeps per plan,
+    the per-line 2 x 2 interface systems, correction planes on the K planes at each end added by the axis-1 sweep's loads
+    (FAST and GENERAL strided kernels) -- against the single-domain HIP step and the oracle"""
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from oracle import adi_oracle as orc
+    rng = np.random.default_rng(sum(shape))
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    dm = dv = None
+    if kind == 'holes':
+        mask = rng.random(shape) > 0.06
+    elif kind == 'ellipsoid':
+        g = np.meshgrid(*[(np.arange(s) + 0.5) / s - 0.5 for s in shape], indexing='ij')
+        mask = (g[0] / 0.49) ** 2 + (g[1] / 0.46) ** 2 + (g[2] / 0.47) ** 2 <= 1.0
+    else:
+        mask = rng.random(shape) > 0.02
+        dm = (rng.random(shape) < 0.01) & mask
+        dv = rng.uniform(100.0, 400.0, shape)
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask, T0=rng.uniform(20.0, 1200.0, shape),
+             dir_mask=dm, dir_value=dv, neumann={'x-': 3e5, 'y+': 2e5, 'z-': 1e4},
+             robin_h={'x-': 300.0, 'x+': 80.0, 'y-': rng.uniform(100.0, 600.0, shape), 'z+': 500.0}, Tinf=20.0, theta=0.5,
+             dt=cfl * dx * dx / alpha, nsteps=3, births=None)
+    modes = set()
+    got = _run_slabs(c, len(sizes), sizes, 3, dict(opts, allow_deferred_lines=True), modes)
+    assert modes == {'deferred_lines'}, modes
+    want = run_cart_case(hip, c)['T_final']
+    assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
+    assert rel_linf(got, run_cart_case(orc, c)['T_final']) <= 1e-10
     assert np.array_equal(got[~mask], c['T0'][~mask])
