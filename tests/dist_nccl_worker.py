@@ -2,7 +2,7 @@
 hand:  python -m torch.distributed.run --nnodes=1 --nproc-per-node W --master-addr 127.0.0.1 --master-port P
 tests/dist_nccl_worker.py).  Every rank builds the same seeded global case, steps its slab with SlabStepper + HipEngine
 over torch.distributed 'nccl' (= RCCL), the slabs are gathered on rank 0 and compared with the one-domain HIP step of
-the whole grid computed there: <= 1e-12 relative L-inf in every interface form (window, slab / dots, exact, deferred).
+the whole grid computed there: <= 1e-12 relative L-inf in every interface form (deferred with per-line solutions, window, slab / dots, exact, deferred).
 Exit code 0 = all forms agree; the process group is created before any other GPU work, as RCCL wants it."""
 import os
 import sys
@@ -40,13 +40,14 @@ def main():
     worst = 0.0
     failures = []
     mask_voids = mask
-    for cfl, opts, nsteps in ((0.05, {}, 3), (150.0, {}, 3), (150.0, dict(allow_dots=False), 2), (300.0, dict(force_exact=True), 2),
-                              (3.0, dict(solid=True), 3)):
+    for cfl, opts, nsteps in ((0.05, {}, 3), (0.05, dict(allow_deferred_lines=False), 3), (150.0, {}, 3),
+                              (150.0, dict(allow_dots=False), 2), (300.0, dict(force_exact=True), 2), (3.0, dict(solid=True), 3)):
         mask = np.ones(shape, bool) if opts.get('solid') else mask_voids      # all-solid: the deferred form
         prm = hip.Params(cfl * dx * dx / alpha, 0.5)
         st = dist_slab.SlabStepper(mask[i0:i1], dx, mat, prm, 20.0, robin_h=300.0, neumann={'x+': 2e5},
                                    comm=dist_slab.TorchDistComm())
         st._allow_dots = opts.get('allow_dots', True); st._force_exact = opts.get('force_exact', False)
+        st._allow_deferred_lines = opts.get('allow_deferred_lines', True)      # (voids + decay: the per-line deferred form)
         T = hip.to_device(np.ascontiguousarray(T0[i0:i1]))
         for s in range(nsteps):
             T = st.step(T, prefetch_halo=(s + 1 < nsteps))
