@@ -560,6 +560,7 @@ class SlabStepper:
         self._allow_deferred = True                # False: never the deferred form (zero-boundary solve + correction on load)
         self._allow_deferred_exact = True          # False: thin slabs (no decay) keep the two-pass all-gather form
         self._allow_deferred_lines = True          # False: lines that are not uniform keep the two-pass forms
+        self._plan_steps = None                    # steps taken under the current axis-0 plan (None: no plan yet)
         self._send_g_only = True                   # False: every step exchanges the matrix parts of the interface too
         self._comm_stream, self._use_streams = None, False
         self._halo_ready, self._halo_event = None, None
@@ -805,7 +806,12 @@ class SlabStepper:
                self._allow_fused, self._allow_window, self._keep_r0, self._allow_dots, self._allow_deferred,
                self._allow_deferred_exact)
         if self._a0_key == key:
+            self._plan_steps += 1
             return self._a0
+        # a plan that lives for a few steps only (a layer-birth loop: every birth changes the mask) does not repay the two
+        # extra sweeps and host synchronisations the per-line deferred form costs per plan; the same on every rank
+        short_lived = self._plan_steps is not None and self._plan_steps < 16
+        self._plan_steps = 0
         E, v = self.engine, self.variant
         self._streams()
         nl, fl, pk = self.nlines, self.flags_int, self.packs_int[0]
@@ -880,7 +886,7 @@ class SlabStepper:
         # Lines that are not uniform (curved solids, voids, Dirichlet cells): the same algebra with the two homogeneous solutions
         # of EVERY line, where they have decayed across every slab ('deferred_lines', include/adi_hip.h ABI v17).  Collective.
         if (self._allow_deferred and self._allow_deferred_lines and hasattr(E, 'homogeneous_solution') and not self._force_exact
-                and self.nxl >= 2 and prm.theta * gam > 0.0):
+                and not short_lived and self.nxl >= 2 and prm.theta * gam > 0.0):
             plan = self._plan_deferred_lines(fl, pk, gam, bool(float(alld[:, 1].min()) >= 1.0))
             if plan is not None:
                 self._a0_key, self._a0 = key, plan
@@ -1128,6 +1134,7 @@ class SlabStepper:
         allok = self.engine.vec(self.world)
         self.comm.all_gather(allok, ok)                 # the ranks must not end up in different configurations
         self._allow_deferred = keep[2]
+        self._plan_steps = None                   # the plans of this check do not count as short-lived ones
         if float(allok.min()) >= 1.0:
             self._no_overlap, self._force_exact = keep[:2]
         return err, not self._no_overlap
