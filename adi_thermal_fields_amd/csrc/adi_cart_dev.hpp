@@ -486,7 +486,8 @@ __device__ __forceinline__ double2 corr_weights(const SweepScal &s, long to)
     return w;
 }
 template <int M>
-__device__ __forceinline__ void corr_apply(const SweepScal &s, double2 w, long to, unsigned off8, unsigned st8, double (&d)[M])
+__device__ __forceinline__ void corr_apply(const SweepScal &s, double2 w, long to, unsigned off8, unsigned st8, double (&d)[M],
+                                           bool inside)
 {
     if (w.x != 0.0) {
         const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc((void *)s.c_lo, 0, (int)s.c_bytes, 0x00020000);
@@ -494,11 +495,18 @@ __device__ __forceinline__ void corr_apply(const SweepScal &s, double2 w, long t
             const long pl = to < s.c_np ? to : s.c_np - 1;
             const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void *)(s.c_wl + pl * s.c_ps), 0, (int)s.c_bytes, 0x00020000);
 #pragma unroll
-            for (int r = 0; r < M; ++r)
-                d[r] = __builtin_fma(buf_load_f64(rW, off8 + (unsigned)r * st8, 0u), buf_load_f64(rL, off8 + (unsigned)r * st8, 0u), d[r]);
+            for (int r = 0; r < M; ++r) {
+                const unsigned vo = inside ? off8 : off8 + (unsigned)r * st8, so = inside ? (unsigned)r * st8 : 0u;
+                d[r] = __builtin_fma(buf_load_f64(rW, vo, so), buf_load_f64(rL, vo, so), d[r]);
+            }
         } else {
+            if (inside) {                  // every row of the tile lies inside the plane: scalar row offsets (0.02 ms at 512^3)
 #pragma unroll
-            for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.x, buf_load_f64(rL, off8 + (unsigned)r * st8, 0u), d[r]);
+                for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.x, buf_load_f64(rL, off8, (unsigned)r * st8), d[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.x, buf_load_f64(rL, off8 + (unsigned)r * st8, 0u), d[r]);
+            }
         }
     }
     if (w.y != 0.0) {
@@ -507,11 +515,18 @@ __device__ __forceinline__ void corr_apply(const SweepScal &s, double2 w, long t
             const long q = s.c_n - 1 - to, ph = q < s.c_np ? q : s.c_np - 1;
             const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void *)(s.c_wh + ph * s.c_ps), 0, (int)s.c_bytes, 0x00020000);
 #pragma unroll
-            for (int r = 0; r < M; ++r)
-                d[r] = __builtin_fma(buf_load_f64(rW, off8 + (unsigned)r * st8, 0u), buf_load_f64(rH, off8 + (unsigned)r * st8, 0u), d[r]);
+            for (int r = 0; r < M; ++r) {
+                const unsigned vo = inside ? off8 : off8 + (unsigned)r * st8, so = inside ? (unsigned)r * st8 : 0u;
+                d[r] = __builtin_fma(buf_load_f64(rW, vo, so), buf_load_f64(rH, vo, so), d[r]);
+            }
         } else {
+            if (inside) {
 #pragma unroll
-            for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.y, buf_load_f64(rH, off8 + (unsigned)r * st8, 0u), d[r]);
+                for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.y, buf_load_f64(rH, off8, (unsigned)r * st8), d[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.y, buf_load_f64(rH, off8 + (unsigned)r * st8, 0u), d[r]);
+            }
         }
     }
 }

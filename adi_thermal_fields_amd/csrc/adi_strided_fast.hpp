@@ -85,7 +85,8 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
     if constexpr (!FUSE) {
         // deferred interface correction of a slab decomposition (SweepScal::c_*): block-uniform, off in ordinary sweeps
         if (s.c_w != nullptr)
-            corr_apply<M>(s, corr_weights(s, to), to, (voff + (unsigned)(ti * LINES)) * 8u, (unsigned)(g.stride * 8), d);
+            corr_apply<M>(s, corr_weights(s, to), to, (voff + (unsigned)(ti * LINES)) * 8u, (unsigned)(g.stride * 8), d,
+                          Lp * M == g.n && (ti + 1) * LINES <= g.n_inner);
     }
     double a0, b0, aS, bS, cS;
     fast_segment_ends<M, HAS_DIR, HAS_Q, (FC ? 1 : 2)>(coeff, dval, qf, g, base, r0, f0, fS, dirS, s, d, a0, b0, aS, bS, cS);

@@ -985,7 +985,9 @@ class SlabStepper:
         # where to look: the reach of the uniform row's solution plus a margin (a run that ends in a line start reflects);
         # what decides is the check below
         K = min(n, int(E.deferred_setup(n, prm.theta, gam, self.DECAY_TOL)['reach']) + 8)
-        ok = K < n
+        # ... and where it pays: the axis-1 sweep reads 2 K weight planes, the two-pass forms the slab a second time -- at
+        # K = 399 of 512 planes (cfl 200) the two were level (2.26 against 2.19 - 2.46 ms from box to box), at K = 183 1.97 : 2.47
+        ok = K < n and 5 * K <= 3 * n
         om, Wlo, Whi = {}, None, None
         if ok and not first:
             W = E.homogeneous_solution(self.variant, self.Lint, fl, pk, prm.theta, gam, prm.dt, True)

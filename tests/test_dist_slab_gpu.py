@@ -335,13 +335,13 @@ def test_slabs_on_ragged_planes(shape, kind, world, opts):
 
 
 @pytest.mark.parametrize('shape,kind,sizes,cfl,opts', [
-    ((256, 16, 64), 'holes', [64] * 4, 3.0, dict(prefetch=True)),                              # FAST kernels, voids in every line
-    ((256, 16, 64), 'holes', [64] * 4, 3.0, dict(prefetch=True, allow_fused=False)),
-    ((256, 48, 64), 'ellipsoid', [64] * 4, 3.0, dict(prefetch=True)),                          # a curved solid across all slabs
-    ((254, 16, 64), 'dirichlet', [64, 62, 64, 64], 3.0, dict(prefetch=True)),                  # Dirichlet cells, uneven slabs
-    ((1024, 16, 32), 'ellipsoid', [512, 512], 200.0, dict(prefetch=True)),                     # the bench's slab thickness and cfl
-    ((192, 70, 90), 'ellipsoid', [64] * 3, 1.0, dict(prefetch=True)),                          # padded planes
-    ((192, 24, 40), 'holes', [64] * 3, 1.0, dict(prefetch=True, no_pad=True)),                 # GENERAL axis-1 kernels
+    ((256, 16, 64), 'holes', [64] * 4, 0.3, dict(prefetch=True)),                              # FAST kernels, voids in every line
+    ((256, 16, 64), 'holes', [64] * 4, 0.3, dict(prefetch=True, allow_fused=False)),
+    ((256, 48, 64), 'ellipsoid', [64] * 4, 0.3, dict(prefetch=True)),                          # a curved solid across all slabs
+    ((254, 16, 64), 'dirichlet', [64, 62, 64, 64], 0.3, dict(prefetch=True)),                  # Dirichlet cells, uneven slabs
+    ((1024, 16, 32), 'ellipsoid', [512, 512], 40.0, dict(prefetch=True)),                      # the bench's slab thickness, K = 183
+    ((192, 70, 90), 'ellipsoid', [64] * 3, 0.3, dict(prefetch=True)),                          # padded planes
+    ((192, 24, 40), 'holes', [64] * 3, 0.3, dict(prefetch=True, no_pad=True)),                 # GENERAL axis-1 kernels
 ])
 def test_slabs_deferred_form_with_per_line_solutions(shape, kind, sizes, cfl, opts):
     """lines that are not uniform ('deferred_lines', ABI v17): per-line homogeneous solutions from two axis-0 sweeps per plan,
