@@ -166,3 +166,23 @@ def test_contiguous_lines_with_a_segment_count_that_is_not_a_power_of_two(nz):
             else:
                 want = orc.sweep_axis(2, np.array(c['T0']), grid, mat, prm, packs[2], 20.0)
         assert rel_linf(got, want) <= 1e-12, (nz, kind, rel_linf(got, want))
+
+
+@pytest.mark.gpu
+def test_frame_output_of_a_padded_field(tmp_path):
+    """a DeviceField on padded extents through the frame writers: the logical box, byte for byte"""
+    import adi_thermal_fields_amd.adi3d_hip_coeff as hip
+    from adi_thermal_fields_amd import frame_io as fio
+    rng = np.random.default_rng(9)
+    shape = (70, 66, 37)
+    T = rng.uniform(20.0, 900.0, shape)
+    dev = hip.to_device(T)
+    assert hip.Layout.of(dev.t).padded
+    assert fio.pack_frame_f32be(dev) == T.reshape(-1, order='F').astype('>f4').tobytes()
+    a, b = str(tmp_path / 'a.vtk'), str(tmp_path / 'b.vtk')
+    fio.write_vtk_structured_points(a, T, 5e-4, field_name='Temp')
+    fio.write_vtk_structured_points(b, dev, 5e-4, field_name='Temp')
+    assert open(a, 'rb').read() == open(b, 'rb').read()
+    p = str(tmp_path / 'f.npy')
+    fio.write_npy(p, dev)
+    assert np.array_equal(np.load(p), T)
