@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libadi_hip.so')
 STAMP_SRC = 'adi_stamp.hip'
-SOURCES = ['adi_cart_api.hip', 'adi_explicit.hip', 'adi_sweep_contig.hip', 'adi_sweep_contig_x.hip', 'adi_sweep_strided.hip', 'adi_sweep_strided_x.hip', 'adi_sweep_strided_y.hip', 'adi_sweep_strided_fc.hip', 'adi_sweep_strided_fx.hip', 'adi_sweep_strided_fy.hip', 'adi_condense.hip', 'adi_cyl.hip', 'adi_ctx.hip', 'adi_morph.hip', STAMP_SRC]
-HEADERS = ['adi_core.hpp', 'adi_common.hpp', 'adi_cart_dev.hpp', 'adi_cart_host.hpp', 'adi_strided_dev.hpp', 'adi_strided_fast.hpp', 'adi_contig_dev.hpp', os.path.join('..', '..', 'include', 'adi_hip.h')]
+SOURCES = ['adi_cart_api.hip', 'adi_explicit.hip', 'adi_sweep_contig.hip', 'adi_sweep_contig_x.hip', 'adi_sweep_strided.hip', 'adi_sweep_strided_x.hip', 'adi_sweep_strided_y.hip', 'adi_sweep_strided_fc.hip', 'adi_sweep_strided_fx.hip', 'adi_sweep_strided_fy.hip', 'adi_sweep_strided_gc.hip', 'adi_sweep_strided_gk.hip', 'adi_condense.hip', 'adi_cyl.hip', 'adi_ctx.hip', 'adi_morph.hip', STAMP_SRC]
+HEADERS = ['adi_core.hpp', 'adi_common.hpp', 'adi_cart_dev.hpp', 'adi_cart_host.hpp', 'adi_strided_dev.hpp', 'adi_strided_fast.hpp', 'adi_strided_general.hpp', 'adi_contig_dev.hpp', os.path.join('..', '..', 'include', 'adi_hip.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fno-fast-math', '-Wall',
          '-Wno-unused-function']
@@ -65,9 +65,11 @@ def build(force=False, verbose=False):
             jobs.append([HIPCC] + FLAGS + PREFIX_MAP + ['-c', s, '-o', o])
 
     def run(cmd):
-        if verbose:
-            print(' '.join(cmd), flush=True)
+        import time
+        t0 = time.time()
         subprocess.check_call(cmd)
+        if verbose:
+            print('%6.1f s  %s' % (time.time() - t0, ' '.join(cmd[-4:])), flush=True)
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))

@@ -49,9 +49,8 @@ __device__ __forceinline__ void condense_tile_general(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ cond, long nlines, const LineGeom &g, int Lp, int LINES, int tiles_inner, long tile,
-    const SweepScal &s, double *sm, const Fuse &fz = Fuse())
+    const SweepScal &s, double *sm, const Fuse &fz, const int tid)
 {
-    const int tid = threadIdx.x;
     const long to = (long)((unsigned)tile / (unsigned)tiles_inner);   // block-uniform, < 2^31 tiles
     const int ti = (int)(tile - to * tiles_inner);
     const int kk = tid & (LINES - 1), sg = tid >> (__ffs(LINES) - 1);   // LINES is a power of two
@@ -64,7 +63,7 @@ __device__ __forceinline__ void condense_tile_general(
         // same assembly as the solve pass, but the end couplings stay in a[0] / c[n-1] (they are the
         // aF, aL / cF, cL of the slab)
         SegRaw<M> R;
-        load_segment_raw<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R, fz);
+        load_segment_raw<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, g, base, r0, active, s, R, fz, nullptr, tid);
         if (FUSE && fz.r0_out != nullptr) {
 #pragma unroll
             for (int r = 0; r < M; ++r)
@@ -88,16 +87,18 @@ __global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_condense_strided(
     extern __shared__ __align__(16) double sm[];
     if (queue == nullptr) {
         condense_tile_general<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp, LINES,
-                                                       tiles_inner, xcd_chunk_tile(blockIdx.x, ntiles), s, sm, fz);
+                                                       tiles_inner, xcd_chunk_tile(blockIdx.x, ntiles), s, sm, fz, (int)threadIdx.x);
     } else {
         const long cnt = (long)queue[0] * ratio;
         for (long i = blockIdx.x; i < cnt; i += gridDim.x) {
             const long u = queue[1 + (unsigned)i / (unsigned)ratio];
             const long to = (long)((unsigned)u / (unsigned)tiles_inner_f);
             const long tig = (u - to * tiles_inner_f) * ratio + ((unsigned)i % (unsigned)ratio);
+            int tid = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid));      // (keeps the per-row offsets out of the loop-carried state, see k_sweep_strided)
             if (tig < tiles_inner)
                 condense_tile_general<M, HAS_DIR, HAS_Q, FUSE>(in, flags, coeff, dmask, dval, qf, cond, nlines, g, Lp,
-                                                               LINES, tiles_inner, to * tiles_inner + tig, s, sm, fz);
+                                                               LINES, tiles_inner, to * tiles_inner + tig, s, sm, fz, tid);
             __syncthreads();
         }
     }

@@ -5,34 +5,58 @@
 
 namespace adi {
 
+// The raw rows of a segment.  The flags bytes stay packed four to a register and the Dirichlet marks one bit per row until the
+// row is assembled: as `unsigned fb[M]; bool dirb[M]` they held 2*M registers from the first load to the last assembled row of a
+// kernel that sits at its 128-VGPR budget (the 42 B/cell kernel: 3 spilled VGPRs, 16 B of scratch; none with the packed form).
 template <int M>
 struct SegRaw {
     double vin[M], vco[M], vdv[M], vq[M];
-    unsigned fb[M];
-    bool dirb[M];
+    unsigned fw[(M + 3) / 4];
+    unsigned dw;
+    __device__ __forceinline__ unsigned f(int r) const { return (fw[r >> 2] >> (8 * (r & 3))) & 0xffu; }
+    __device__ __forceinline__ bool dir(int r) const { return (dw >> r) & 1u; }
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < (M + 3) / 4; ++i) fw[i] = 0u;
+        dw = 0u;
+    }
+    __device__ __forceinline__ void or_f(int r, unsigned byte) { fw[r >> 2] |= (byte & 0xffu) << (8 * (r & 3)); }
+    __device__ __forceinline__ void or_dir(int r, bool on) { dw |= (on ? 1u : 0u) << r; }
 };
+// bit r of the result: byte r of the packed 64-bit word is non-zero (Dirichlet marks of 8 rows)
+__device__ __forceinline__ unsigned nonzero_bytes8(unsigned lo, unsigned hi)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        m |= (((lo >> (8 * r)) & 0xffu) != 0u ? 1u : 0u) << r;
+        m |= (((hi >> (8 * r)) & 0xffu) != 0u ? 1u : 0u) << (r + 4);
+    }
+    return m;
+}
 
-template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false>
+// FCM: source of the coefficient / flux of an exposed row (pack_co): 0 run time, 1 the flags, 2 the arrays
+template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false, int FCM = 0>
 __device__ __forceinline__ void load_segment_raw(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     const LineGeom &g, long base, int r0, bool active, const SweepScal &s, SegRaw<M> &R, const Fuse &fz = Fuse(),
-    uint8_t *bstrip = nullptr)
+    uint8_t *bstrip = nullptr, int tid = threadIdx.x)
 {
     // bstrip != nullptr (block-uniform; M == 8, 8-line tiles, whole tile, 8-byte aligned byte arrays): the flag and
     // Dirichlet bytes of a segment -- 8 rows x 8 lines -- are fetched as ONE 8-byte load per lane (lane kk takes row kk)
     // and transposed through a wave-private LDS strip, instead of 8 + 8 single-byte loads per thread.  These kernels
     // are bound by the issue rate of the vector-memory pipe (SQ_WAIT_INST_ANY 30 % of the wave cycles at 56 memory
     // instructions per 8 cells), not by bytes.
-    unsigned long long dpk = 0;
+    R.clear();
     if (bstrip != nullptr) {
         if constexpr (M == 8) {
-            const int kk = threadIdx.x & 7;
+            const int kk = tid & 7;
             const long prow = base - kk + (long)(r0 + kk) * g.stride;       // row r0+kk, first line of the tile
             const unsigned long long fq = *reinterpret_cast<const unsigned long long *>(flags + prow);
             unsigned long long dq = 0;
             if (HAS_DIR) dq = *reinterpret_cast<const unsigned long long *>(dmask + prow);
-            uint8_t *st = bstrip + (threadIdx.x >> 3) * (HAS_DIR ? 128 : 64);   // this segment's strip: [line][row]
+            uint8_t *st = bstrip + (tid >> 3) * (HAS_DIR ? 128 : 64);   // this segment's strip: [line][row]
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
                 st[l * 8 + kk] = (uint8_t)(fq >> (8 * l));
@@ -40,17 +64,18 @@ __device__ __forceinline__ void load_segment_raw(
             }
             wave_lds_fence();
             const unsigned long long fpk = *reinterpret_cast<const unsigned long long *>(st + kk * 8);
+            unsigned long long dpk = 0;
             if (HAS_DIR) dpk = *reinterpret_cast<const unsigned long long *>(st + 64 + kk * 8);
             wave_lds_fence();
-#pragma unroll
-            for (int r = 0; r < M; ++r) R.fb[r] = (unsigned)(fpk >> (8 * r)) & 0xffu;
+            R.fw[0] = (unsigned)fpk; R.fw[1] = (unsigned)(fpk >> 32);
+            R.dw = nonzero_bytes8((unsigned)dpk, (unsigned)(dpk >> 32));
         }
     }
 #pragma unroll
     for (int r = 0; r < M; ++r) {
         const bool ok = active && (r0 + r) < g.n;
         const long p = base + (long)(r0 + r) * g.stride;
-        if (bstrip == nullptr) R.fb[r] = ok ? flags[p] : 0u;
+        if (bstrip == nullptr) R.or_f(r, ok ? flags[p] : 0u);
         R.vin[r] = ok ? in[p] : 0.0;
     }
     if (FUSE) {
@@ -60,7 +85,7 @@ __device__ __forceinline__ void load_segment_raw(
 #pragma unroll
         for (int r = 0; r < M; ++r) {
             const long p = base + (long)(r0 + r) * g.stride;
-            const unsigned f = R.fb[r];
+            const unsigned f = R.f(r);
             const double cur = R.vin[r];
             double im, ip;
             if (r > 0) im = prev; else im = (f & 2u) ? in[p - g.stride] : 0.0;
@@ -76,13 +101,15 @@ __device__ __forceinline__ void load_segment_raw(
     for (int r = 0; r < M; ++r) {
         const bool ok = active && (r0 + r) < g.n;
         const long p = base + (long)(r0 + r) * g.stride;
-        const bool need = ok && (!s.sparse || axis_exposed(R.fb[r], g.lbit));
-        R.dirb[r] = false;
-        if (HAS_DIR) R.dirb[r] = (bstrip != nullptr) ? (((dpk >> (8 * r)) & 0xffull) != 0) : (ok && dmask[p] != 0);
-        const bool hl = (R.fb[r] >> g.lbit) & 1u, hh = (R.fb[r] >> (g.lbit + 1)) & 1u;
-        R.vco[r] = need ? pack_co(s, coeff + p, hl, hh) : 0.0;                     // (fconst only comes with sparse)
-        R.vq[r] = (HAS_Q && need) ? pack_q<HAS_Q>(s, qf + p, hl, hh) : 0.0;
-        R.vdv[r] = (HAS_DIR && ok && (!s.sparse || R.dirb[r])) ? dval[p] : 0.0;
+        const unsigned f = R.f(r);
+        const bool need = ok && (!s.sparse || axis_exposed(f, g.lbit));
+        if (HAS_DIR && bstrip == nullptr) R.or_dir(r, ok && dmask[p] != 0);
+        const bool hl = (f >> g.lbit) & 1u, hh = (f >> (g.lbit + 1)) & 1u;
+        if constexpr (FCM != 1) {                                                  // (FCM == 1: assemble_one forms them)
+            R.vco[r] = need ? pack_co<FCM>(s, coeff + p, hl, hh) : 0.0;            // (fconst only comes with sparse)
+            R.vq[r] = (HAS_Q && need) ? pack_q<HAS_Q, FCM>(s, qf + p, hl, hh) : 0.0;
+        }
+        R.vdv[r] = (HAS_DIR && ok && (!s.sparse || R.dir(r))) ? dval[p] : 0.0;
     }
 }
 
@@ -115,21 +142,23 @@ __device__ __forceinline__ unsigned packed_byte(const unsigned (&w)[M / 4], int 
 // scalar registers, ONE 32-bit per-thread offset for every load and store -- the flat-addressed form above keeps a 64-bit
 // pointer per row alive from the first load to the last store (32 VGPRs at 8 rows), which is what pushed the 42 B/cell
 // kernel over its 128-VGPR budget into scratch.
-template <int M, bool HAS_DIR, bool HAS_Q>
+template <int M, bool HAS_DIR, bool HAS_Q, int FCM = 0>
 __device__ __forceinline__ void load_segment_raw_buf(
     const double *__restrict__ in_t, const uint8_t *__restrict__ flags_t, const double *__restrict__ coeff_t,
     const uint8_t *__restrict__ dmask_t, const double *__restrict__ dval_t, const double *__restrict__ qf_t,
-    const LineGeom &g, unsigned voff, const SweepScal &s, SegRaw<M> &R, uint8_t *bstrip, uint8_t *bstrip16 = nullptr)
+    const LineGeom &g, unsigned voff, const SweepScal &s, SegRaw<M> &R, uint8_t *bstrip, uint8_t *bstrip16 = nullptr,
+    unsigned tid = threadIdx.x)
 {
     const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void *)in_t, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void *)flags_t, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void *)coeff_t, 0, 0x7fffffff, 0x00020000);
     const unsigned st = (unsigned)g.stride, st8 = st * 8u, vb = voff * 8u;
-    unsigned long long dpk = 0;
+    R.clear();
+    const bool packed = bstrip != nullptr || bstrip16 != nullptr;
     if (bstrip != nullptr) {
         if constexpr (M == 8) {
             // flag / Dirichlet bytes of the segment (8 rows x 8 lines) as ONE 8-byte load per lane, transposed in LDS
-            const unsigned kk = threadIdx.x & 7u;
+            const unsigned kk = tid & 7u;
             const unsigned prow = voff - kk + kk * st;                          // row kk of the segment, first line of the tile
             const u32x2 fq = __builtin_amdgcn_raw_buffer_load_b64(rF, prow, 0u, 0);
             u32x2 dq = {0u, 0u};
@@ -137,7 +166,7 @@ __device__ __forceinline__ void load_segment_raw_buf(
                 const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)dmask_t, 0, 0x7fffffff, 0x00020000);
                 dq = __builtin_amdgcn_raw_buffer_load_b64(rM, prow, 0u, 0);
             }
-            uint8_t *sp = bstrip + (threadIdx.x >> 3) * (HAS_DIR ? 128 : 64);   // this segment's strip: [line][row]
+            uint8_t *sp = bstrip + (tid >> 3) * (HAS_DIR ? 128 : 64);   // this segment's strip: [line][row]
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
                 sp[l * 8 + kk] = (uint8_t)((l < 4 ? fq.x : fq.y) >> (8 * (l & 3)));
@@ -145,39 +174,37 @@ __device__ __forceinline__ void load_segment_raw_buf(
             }
             wave_lds_fence();
             const unsigned long long fpk = *reinterpret_cast<const unsigned long long *>(sp + kk * 8);
+            unsigned long long dpk = 0;
             if (HAS_DIR) dpk = *reinterpret_cast<const unsigned long long *>(sp + 64 + kk * 8);
             wave_lds_fence();
-#pragma unroll
-            for (int r = 0; r < M; ++r) R.fb[r] = (unsigned)(fpk >> (8 * r)) & 0xffu;
+            R.fw[0] = (unsigned)fpk; R.fw[1] = (unsigned)(fpk >> 32);
+            R.dw = nonzero_bytes8((unsigned)dpk, (unsigned)(dpk >> 32));
         }
     }
     if (bstrip16 != nullptr) {
         if constexpr (M == 8) {
             // 16-line tiles: the 8 rows x 16 lines of flag / Dirichlet bytes as one 16-byte load in 8 of the 16 lanes
-            const unsigned k16 = threadIdx.x & 15u;
-            uint8_t *sp = bstrip16 + (threadIdx.x >> 4) * 128;
+            const unsigned k16 = tid & 15u;
+            uint8_t *sp = bstrip16 + (tid >> 4) * 128;
             unsigned fw[2], dw[2] = {0u, 0u};
             load_bytes_packed16<8>(flags_t, voff - k16, st, (int)k16, sp, fw);
             if (HAS_DIR) load_bytes_packed16<8>(dmask_t, voff - k16, st, (int)k16, sp, dw);
-#pragma unroll
-            for (int r = 0; r < M; ++r) R.fb[r] = packed_byte<8>(fw, r);
-            dpk = ((unsigned long long)dw[1] << 32) | dw[0];
+            R.fw[0] = fw[0]; R.fw[1] = fw[1];
+            R.dw = nonzero_bytes8(dw[0], dw[1]);
         }
     }
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-        if (bstrip == nullptr && bstrip16 == nullptr) R.fb[r] = __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, 0);
+        if (!packed) R.or_f(r, __builtin_amdgcn_raw_buffer_load_b8(rF, voff, (unsigned)r * st, 0));
         R.vin[r] = buf_load_f64(rT, vb, (unsigned)r * st8);
     }
     const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void *)(HAS_Q ? qf_t : coeff_t), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void *)(HAS_DIR ? dval_t : coeff_t), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void *)(HAS_DIR ? dmask_t : flags_t), 0, 0x7fffffff, 0x00020000);
-    if (!s.sparse) {                                // dense packs: every array in full, unconditional loads
+    if (FCM != 1 && !s.sparse) {                    // dense packs: every array in full, unconditional loads
 #pragma unroll
         for (int r = 0; r < M; ++r) {
-            R.dirb[r] = false;
-            if (HAS_DIR) R.dirb[r] = (bstrip != nullptr || bstrip16 != nullptr) ? (((dpk >> (8 * r)) & 0xffull) != 0)
-                                                         : (__builtin_amdgcn_raw_buffer_load_b8(rM, voff, (unsigned)r * st, 0) != 0);
+            if (HAS_DIR && !packed) R.or_dir(r, __builtin_amdgcn_raw_buffer_load_b8(rM, voff, (unsigned)r * st, 0) != 0);
             R.vco[r] = buf_load_f64(rC, vb, (unsigned)r * st8);
             R.vq[r] = HAS_Q ? buf_load_f64(rQ, vb, (unsigned)r * st8) : 0.0;
             R.vdv[r] = HAS_DIR ? buf_load_f64(rV, vb, (unsigned)r * st8) : 0.0;
@@ -185,29 +212,42 @@ __device__ __forceinline__ void load_segment_raw_buf(
     } else {
 #pragma unroll
         for (int r = 0; r < M; ++r) {
-            const bool need = axis_exposed(R.fb[r], g.lbit);
-            R.dirb[r] = false;
-            if (HAS_DIR) R.dirb[r] = (bstrip != nullptr || bstrip16 != nullptr) ? (((dpk >> (8 * r)) & 0xffull) != 0)
-                                                         : (__builtin_amdgcn_raw_buffer_load_b8(rM, voff, (unsigned)r * st, 0) != 0);
-            if (s.fconst) {
-                const bool hl = (R.fb[r] >> g.lbit) & 1u, hh = (R.fb[r] >> (g.lbit + 1)) & 1u;
-                R.vco[r] = need ? pack_co(s, nullptr, hl, hh) : 0.0;
-                R.vq[r] = (HAS_Q && need) ? pack_q<HAS_Q>(s, nullptr, hl, hh) : 0.0;
+            const unsigned f = R.f(r);
+            const bool need = axis_exposed(f, g.lbit);
+            if (HAS_DIR && !packed) R.or_dir(r, __builtin_amdgcn_raw_buffer_load_b8(rM, voff, (unsigned)r * st, 0) != 0);
+            if constexpr (FCM == 1) {
+                // (assemble_one forms the coefficients from the flags)
+            } else if (FCM == 0 && s.fconst) {
+                const bool hl = (f >> g.lbit) & 1u, hh = (f >> (g.lbit + 1)) & 1u;
+                R.vco[r] = need ? pack_co<1>(s, nullptr, hl, hh) : 0.0;
+                R.vq[r] = (HAS_Q && need) ? pack_q<HAS_Q, 1>(s, nullptr, hl, hh) : 0.0;
             } else {
                 R.vco[r] = need ? buf_load_f64(rC, vb, (unsigned)r * st8) : 0.0;
                 R.vq[r] = (HAS_Q && need) ? buf_load_f64(rQ, vb, (unsigned)r * st8) : 0.0;
             }
-            R.vdv[r] = (HAS_DIR && R.dirb[r]) ? buf_load_f64(rV, vb, (unsigned)r * st8) : 0.0;
+            R.vdv[r] = (HAS_DIR && R.dir(r)) ? buf_load_f64(rV, vb, (unsigned)r * st8) : 0.0;
         }
     }
 }
 
-template <int M, bool HAS_DIR, bool HAS_Q>
+// FCM == 1 (coefficients from the flags): the loaders leave vco / vq alone and the two numbers are formed here, where the row
+// is assembled -- formed in the loader they were sixteen more values alive across the whole load phase (straight-line selects:
+// the scheduler hoists them all; 80 - 120 B of scratch in the fused builds)
+template <int M, bool HAS_DIR, bool HAS_Q, int FCM = 0>
 __device__ __forceinline__ void assemble_one(const SegRaw<M> &R, int r, int lbit, const SweepScal &s, double &a,
                                              double &b, double &c, double &d)
 {
-    assemble_row<HAS_DIR, HAS_Q>(R.fb[r] & 1u, (R.fb[r] >> lbit) & 1u, (R.fb[r] >> (lbit + 1)) & 1u, R.dirb[r],
-                                 R.vin[r], R.vco[r], R.vdv[r], R.vq[r], s, a, b, c, d);
+    const unsigned f = R.f(r);
+    const bool hl = (f >> lbit) & 1u, hh = (f >> (lbit + 1)) & 1u;
+    double co, q;
+    if constexpr (FCM == 1) {
+        const bool need = axis_exposed(f, lbit);
+        co = need ? pack_co<1>(s, nullptr, hl, hh) : 0.0;
+        q = (HAS_Q && need) ? pack_q<HAS_Q, 1>(s, nullptr, hl, hh) : 0.0;
+    } else {
+        co = R.vco[r]; q = R.vq[r];
+    }
+    assemble_row<HAS_DIR, HAS_Q>(f & 1u, hl, hh, HAS_DIR && R.dir(r), R.vin[r], co, R.vdv[r], q, s, a, b, c, d);
 }
 
 
