@@ -102,9 +102,6 @@ __device__ __forceinline__ void reduced_row(double aS, double bS, double cS, dou
 // (Lp a power of two <= 64, li = lane index inside the line).  Rows outside [0, Lp) are identity.
 __device__ __forceinline__ double pcr_solve(double ra, double rb, double rc, double rd, int li, int Lp)
 {
-#ifdef ADI_EXP_NOPCR      // (timing experiment only: what the interface solve costs; results are wrong)
-    return rd * frcp(rb + ra + rc);
-#endif
     for (int dl = 1; dl < Lp; dl <<= 1) {
         const double inv = frcp(rb);
         const bool hl = (li - dl) >= 0, hh = (li + dl) < Lp;
@@ -221,8 +218,12 @@ __device__ __forceinline__ double &mixed_row(double (&d)[M], int q) { return d[R
 // matrix  (A^-1)_{0,q} = y_q / D  with  D = bu y_0 + s y_1  (row 0).  One FMA for y and one for the dot product per row, one
 // reciprocal at the end; the elimination form it replaces ran a reciprocal chain along the run (~9 dependent fp64
 // operations per row, on a curved solid in two lanes of every line: +17 % on the contiguous sweep of a 512^3 ellipsoid).
-// Growth: y_0 <= (2 + 1/tg)^(L-1); the callers send surface segments to the GENERAL kernels when tg < kMixedMinTg.
-constexpr double kMixedMinTg = 1e-12;
+// Growth: y_0 <= (2 + 1/tg)^(L-1) with L <= M-1 rows, and the FAST kernels hold up to 32 rows per lane (strided axis 1 at 512
+// rows; 30 at 480): y_0 times data of order 1e3 must stay below DBL_MAX, i.e. (2 + 1/tg)^30 < 1e300 -> tg > 1e-10.  The
+// callers send surface segments to the GENERAL kernels when tg < kMixedMinTg = 1e-9 (growth <= 1e270); round 3's 1e-12 was
+// sized for 16-row segments and left tg in [1e-12, 7e-11] on 480 - 512-row lines to overflow into inf / inf.  Such steps
+// (dt a billionth of the cell's diffusion time: residual sub-steps of an event loop) are rare; the GENERAL kernels are exact.
+constexpr double kMixedMinTg = 1e-9;
 template <int M, bool REV, class UC>
 __device__ __forceinline__ void mixed_condense(const UC &U, double (&d)[M], int L, double bmod, double a_c,
                                                double &G, double &A)

@@ -36,8 +36,8 @@ import threading
 import numpy as np
 import torch
 
-__all__ = ['SlabStepper', 'TorchDistComm', 'LocalComm', 'LoopbackComm', 'SelfLoopDistComm', 'HipEngine', 'split_planes',
-           'rccl_env_defaults']
+__all__ = ['SlabStepper', 'TorchDistComm', 'HostStagedDistComm', 'LocalComm', 'LoopbackComm', 'SelfLoopDistComm', 'HipEngine',
+           'split_planes', 'rccl_env_defaults', 'gather_slabs']
 
 
 def rccl_env_defaults():
@@ -100,6 +100,86 @@ class TorchDistComm:
     def all_gather(self, out, inp):
         self.bytes_sent += inp.numel() * inp.element_size() * (self.world - 1)
         self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+
+class HostStagedDistComm(TorchDistComm):
+    """A TEST transport, not a product path: torch.distributed 'gloo' between processes whose fields live on a GPU.  Every
+    payload goes device -> pinned host buffer -> gloo -> pinned host buffer -> device, the copies on the CURRENT stream, so
+    the stream / event ordering SlabStepper sets up around an exchange is the one a RCCL run has.  RCCL refuses a second rank
+    on the same device, gloo does not care: with this transport several REAL processes -- separate HIP contexts, separate
+    allocators, a real rendezvous -- drive HipEngine + SlabStepper on the one GPU of a test box
+    (tests/test_dist_hip_processes.py, `bench.py --transport gloo-staged`)."""
+
+    def __init__(self, group=None):
+        super().__init__(group)
+        self._pin = {}
+
+    def _host(self, tag, t):
+        key = (tag, tuple(t.shape), t.dtype)
+        h = self._pin.get(key)
+        if h is None:
+            h = torch.zeros(tuple(t.shape), dtype=t.dtype).pin_memory() if t.is_cuda else torch.zeros(tuple(t.shape), dtype=t.dtype)
+            self._pin[key] = h
+        return h
+
+    @staticmethod
+    def _wait_stream(t):
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+
+    def exchange_planes(self, send_lo, send_hi, recv_lo, recv_hi):
+        dist, ops, back = self.dist, [], []
+        if self.rank > 0:
+            hs, hr = self._host('s_lo', send_lo), self._host('r_lo', recv_lo)
+            hs.copy_(send_lo, non_blocking=True)
+            ops += [dist.P2POp(dist.isend, hs, self.rank - 1, self.group), dist.P2POp(dist.irecv, hr, self.rank - 1, self.group)]
+            back.append((recv_lo, hr))
+            self.bytes_sent += send_lo.numel() * send_lo.element_size()
+        if self.rank < self.world - 1:
+            hs, hr = self._host('s_hi', send_hi), self._host('r_hi', recv_hi)
+            hs.copy_(send_hi, non_blocking=True)
+            ops += [dist.P2POp(dist.isend, hs, self.rank + 1, self.group), dist.P2POp(dist.irecv, hr, self.rank + 1, self.group)]
+            back.append((recv_hi, hr))
+            self.bytes_sent += send_hi.numel() * send_hi.element_size()
+        if not ops:
+            return
+        self.n_exchanges += 1
+        self._wait_stream(send_lo)
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        for dst, h in back:
+            dst.copy_(h, non_blocking=True)
+        self._wait_stream(send_lo)       # the pinned buffers are reused by the next exchange, possibly issued on another stream
+
+    def all_gather(self, out, inp):
+        self.bytes_sent += inp.numel() * inp.element_size() * (self.world - 1)
+        hi = self._host('ag_i', inp.reshape(-1))
+        ho = self._host('ag_o', out.reshape(-1))
+        hi.copy_(inp.reshape(-1), non_blocking=True)
+        self._wait_stream(inp)
+        self.dist.all_gather_into_tensor(ho, hi, group=self.group)
+        out.view(-1).copy_(ho, non_blocking=True)
+        self._wait_stream(inp)
+
+
+def gather_slabs(local, sizes, group=None, host_staged=False):
+    """The whole field on rank 0 (a tensor on `local`'s device; None on the other ranks) from slabs of sizes[r] planes each.
+    Point-to-point copies of the right sizes (slabs may differ by two planes).  host_staged: through host memory (gloo)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    assert len(sizes) == world and local.shape[0] == sizes[rank], (sizes, tuple(local.shape), rank)
+    mine = local.contiguous()
+    if local.is_cuda:
+        torch.cuda.current_stream(local.device).synchronize()
+    if rank != 0:
+        dist.send(mine.cpu() if host_staged else mine, dst=0, group=group)
+        return None
+    parts = [mine]
+    for r in range(1, world):
+        buf = torch.empty((sizes[r],) + tuple(local.shape[1:]), dtype=local.dtype, device='cpu' if host_staged else local.device)
+        dist.recv(buf, src=r, group=group)
+        parts.append(buf.to(local.device))
+    return torch.cat(parts, dim=0)
 
 
 class LocalComm:
@@ -235,7 +315,10 @@ class HipEngine:
         return self.hip.Layout(nx, ny, nz, sx, phys=(nx, ny, nz))
 
     def vec(self, n):
-        return torch.empty(n, dtype=torch.float64, device=self.device)
+        """plan-time fp64 buffer (receive buffers, interface values, flags): ZERO-filled, so a protocol slip shows as a wrong
+        number and never as a read of uninitialised memory (round 3's one GPU memory fault: 0 / 1 plane flags built on an
+        uninitialised vec()).  Never called per step."""
+        return torch.zeros(n, dtype=torch.float64, device=self.device)
 
     def build_flags(self, L, mask_ext):
         flags = L.empty(torch.uint8, zero=True)
@@ -804,7 +887,7 @@ class SlabStepper:
         prm = self.params
         key = (float(prm.dt), float(prm.theta), self._mask_version, self._force_exact, self._no_overlap,
                self._allow_fused, self._allow_window, self._keep_r0, self._allow_dots, self._allow_deferred,
-               self._allow_deferred_exact)
+               self._allow_deferred_exact, self._allow_deferred_lines)
         if self._a0_key == key:
             self._plan_steps += 1
             return self._a0
@@ -886,7 +969,9 @@ class SlabStepper:
         # Lines that are not uniform (curved solids, voids, Dirichlet cells): the same algebra with the two homogeneous solutions
         # of EVERY line, where they have decayed across every slab ('deferred_lines', include/adi_hip.h ABI v17).  Collective.
         if (self._allow_deferred and self._allow_deferred_lines and hasattr(E, 'homogeneous_solution') and not self._force_exact
-                and not short_lived and self.nxl >= 2 and prm.theta * gam > 0.0):
+                and not short_lived and prm.theta * gam > 0.0):
+            # (every term of this gate is the same on every rank: what depends on the rank's own slab -- its thickness, the decay
+            # of its lines -- is decided inside, behind the all-gather; a rank-local `nxl >= 2` here hung slabs of [8, 1] planes)
             plan = self._plan_deferred_lines(fl, pk, gam, bool(float(alld[:, 1].min()) >= 1.0))
             if plan is not None:
                 self._a0_key, self._a0 = key, plan
@@ -987,7 +1072,7 @@ class SlabStepper:
         K = min(n, int(E.deferred_setup(n, prm.theta, gam, self.DECAY_TOL)['reach']) + 8)
         # ... and where it pays: the axis-1 sweep reads 2 K weight planes, the two-pass forms the slab a second time -- at
         # K = 399 of 512 planes (cfl 200) the two were level (2.26 against 2.19 - 2.46 ms from box to box), at K = 183 1.97 : 2.47
-        ok = K < n and 5 * K <= 3 * n
+        ok = n >= 2 and K < n and 5 * K <= 3 * n
         om, Wlo, Whi = {}, None, None
         if ok and not first:
             W = E.homogeneous_solution(self.variant, self.Lint, fl, pk, prm.theta, gam, prm.dt, True)
@@ -1010,8 +1095,7 @@ class SlabStepper:
         om['lo_next'] = None if last else E.vec(nl_).view(self.ny, self.nz)
         self.comm.exchange_planes(om.get('lo_own', dummy), om.get('hi_own', dummy),
                                   dummy if first else om['hi_prev'], dummy if last else om['lo_next'])
-        w01 = E.vec(n)                     # (vec() is uninitialised memory on the product engine)
-        w01.zero_()
+        w01 = E.vec(n)                     # (zero-filled)
         w01[:K] = 1.0
         return dict(mode='deferred_lines', K=K, fused=fused_ok, dots=False, keep_r0=False, chunks=[], om=om, Wlo=Wlo, Whi=Whi,
                     w01=w01, ulo=E.vec(nl_), uhi=E.vec(nl_), prev_last=E.vec(nl_), next_first=E.vec(nl_))

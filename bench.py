@@ -58,8 +58,15 @@ def parse(argv=None):
     ap.add_argument('--mask', choices=['box', 'ellipsoid'], default='box',
                     help='box: all-solid (the headline workload); ellipsoid: the same box holding a curved solid '
                          '(semi-axes 0.47 / 0.49 / 0.48 of the box), i.e. every in-mask line crosses the surface twice')
-    ap.add_argument('--launch-timeout', type=float, default=1500.0,
-                    help='seconds the self-started ranks of a plain `--gpus N` run may take before they are killed')
+    ap.add_argument('--launch-timeout', type=float, default=480.0,
+                    help='seconds the self-started ranks of a plain `--gpus N` run may take before they are killed (below the '
+                         "driver's own 600 s limit, so that a hang still ends with the tail of the ranks' stderr)")
+    ap.add_argument('--transport', choices=['nccl', 'gloo-staged'], default='nccl',
+                    help='N > 1: nccl = RCCL, one rank per GPU (default, the product path); gloo-staged = a TEST transport that puts '
+                         'every rank on cuda:0 and stages the payloads through pinned host memory (dist_slab.HostStagedDistComm): '
+                         'runs the whole N > 1 code path with real processes on a one-GPU box; the line is marked')
+    ap.add_argument('--pg-timeout', type=float, default=120.0,
+                    help='seconds a collective of the process group may wait before the rank aborts with a stack trace')
     return ap.parse_args(argv)
 
 
@@ -115,7 +122,10 @@ def launch_ranks(nproc, script, script_args, timeout_s, extra_env=None):
 
 def launch_self(a, argv):
     """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks, relay rank 0's line."""
-    rc, line, tail = launch_ranks(a.gpus, os.path.abspath(__file__), argv, a.launch_timeout)
+    # the arguments travel in the environment: torch.distributed.run's own parser claims abbreviations of ITS options among the
+    # script's arguments (`--n 128` is "ambiguous: --nnodes, --nproc-per-node, ...")
+    rc, line, tail = launch_ranks(a.gpus, os.path.abspath(__file__), [], a.launch_timeout,
+                                  extra_env={'ADI_BENCH_ARGV': json.dumps(list(argv))})
     if rc == 0 and line is not None:
         print(line, flush=True)
         return 0
@@ -206,6 +216,95 @@ def emit(text):
         os.write(_STDOUT_FD, (text + '\n').encode())
 
 
+class Collect:
+    """the bench's own small collectives (timings, per-rank records, the barrier): device tensors over nccl, host tensors
+    over gloo (the gloo-staged test transport has no device collectives)"""
+
+    def __init__(self, dist, active, staged, dev):
+        self.dist, self.active, self.staged, self.dev = dist, active, staged, dev
+
+    def _t(self, vals):
+        return torch.tensor(vals, dtype=torch.float64, device='cpu' if self.staged else self.dev)
+
+    def barrier(self):
+        if self.active:
+            self.dist.barrier()
+
+    def max(self, x):
+        if not self.active:
+            return float(x)
+        t = self._t([float(x)])
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_rows(self, vals):
+        """every rank's list of floats -> (world, len) array on every rank"""
+        t = self._t(list(vals))
+        out = torch.empty(self.dist.get_world_size() * t.numel(), dtype=torch.float64, device=t.device)
+        self.dist.all_gather_into_tensor(out, t)
+        return out.view(self.dist.get_world_size(), -1).cpu().numpy()
+
+
+def seeded_planes(i0, i1, ny, nz, seed=1):
+    """planes [i0, i1) of the seeded host field T0[i] = default_rng((seed, i)).uniform(20, 1000, (ny, nz)): every rank can make
+    its own planes, rank 0 the whole field, without anyone generating what it does not need"""
+    out = np.empty((i1 - i0, ny, nz))
+    for i in range(i0, i1):
+        out[i - i0] = np.random.default_rng((seed, i)).uniform(20.0, 1000.0, (ny, nz))
+    return out
+
+
+def parity_vs_one_domain(a, adi, dist_slab, dist, world, rank, mat, prm, dx, Tinf, make_comm, staged, sizes, ny, nz, label):
+    """"the multi-GPU result must equal the 1-GPU result to <= 1e-12".  PARITY_STEPS steps of a grid of
+    sum(sizes) x ny x nz cells cut into this job's slabs (sizes[r] planes on rank r, the interface form SlabStepper picks for
+    them, halos prefetched as in the timed loop) from a seeded host field; the slabs are gathered on rank 0, which takes the
+    same steps on ONE domain with the single-GPU stepper and compares.  Returns the record for the JSON line (rank 0; None
+    elsewhere).  Collective; runs before the timed loop; an exception on any rank is reported in the record, not raised."""
+    PARITY_STEPS = 3
+    nx = int(sum(sizes))
+    i0 = int(sum(sizes[:rank])); i1 = i0 + int(sizes[rank])
+    rec = dict(grid='%dx%dx%d' % (nx, ny, nz), planes_per_rank=[int(v) for v in sizes], steps=PARITY_STEPS, bar=1e-12, what=label)
+    err, form = None, None
+    try:
+        mask = make_mask(a.mask, (i1 - i0, ny, nz), i0, nx)
+        T = adi.to_device(seeded_planes(i0, i1, ny, nz))
+        st = dist_slab.SlabStepper.from_local(T.t, mask, dx, mat, prm, Tinf, robin_h=500.0, comm=make_comm())
+        for s_ in range(PARITY_STEPS):
+            T = st.step(T, prefetch_halo=(s_ + 1 < PARITY_STEPS))
+        torch.cuda.synchronize()
+        form = st.axis0_mode
+        full = dist_slab.gather_slabs(T.t, [int(v) for v in sizes], host_staged=staged)
+        del st, T
+    except Exception as e:          # noqa: BLE001 -- the line must still be printed
+        err, full = '%s: %s' % (type(e).__name__, e), None
+    forms = [None] * world
+    dist.all_gather_object(forms, (form, err))
+    if rank != 0:
+        return None
+    rec['form'] = forms[0][0]
+    rec['forms_agree'] = len(set(f for f, _ in forms)) == 1
+    errs = ['rank %d: %s' % (r_, e) for r_, (_, e) in enumerate(forms) if e]
+    if errs or full is None:
+        rec.update(rel_linf=None, ok=False, error='; '.join(errs) or 'no field gathered')
+        return rec
+    try:
+        gmask = make_mask(a.mask, (nx, ny, nz))
+        grid = adi.Grid3D(nx, ny, nz, dx, gmask)
+        one = adi.StagedStepper(grid, mat, prm, adi.precompute_coeff_packs_unified(grid, mat, robin_h=500.0), Tinf)
+        W = adi.to_device(seeded_planes(0, nx, ny, nz))
+        for _ in range(PARITY_STEPS):
+            W = one.step(W)
+        den = float(W.t.abs().max().item())
+        rel = float((full - W.t).abs().max().item()) / (den if den > 0 else 1.0)
+        rec.update(rel_linf=rel, ok=bool(rel <= rec['bar'] and rec['forms_agree']),
+                   against='adi3d_hip_coeff.StagedStepper on the whole grid on rank 0 (one domain), same seeded T0 and mask')
+        del one, W, grid, full
+        torch.cuda.empty_cache()
+    except Exception as e:          # noqa: BLE001
+        rec.update(rel_linf=None, ok=False, error='one-domain leg on rank 0: %s: %s' % (type(e).__name__, e))
+    return rec
+
+
 def main_cyl(a):
     """BASELINE.json configs[3] / SURVEY.md 8(d) config 4: cylindrical (r, phi, z) = 128 x 256 x 512, dr = dz = 2.5e-4,
     BE, dt = 0.05, RobinR(400, 20), z: neumann0 / robin h = 500, T0 = 20 with the top 16 z-planes at 1000.
@@ -220,8 +319,9 @@ def main_cyl(a):
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     if world > 1:
+        import datetime
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=a.pg_timeout))
     import adi_thermal_fields_amd.adi3d_hip_cyl as cyl
     nr, nphi, nz = 128, 256, 512
     g = cyl.GridCyl(nr, nphi, nz, 2.5e-4, 2 * np.pi / nphi, 2.5e-4, 0.032)
@@ -327,7 +427,11 @@ def measured_traffic(kernel, config='cart'):
 
 
 def main(argv=None):
-    argv = sys.argv[1:] if argv is None else list(argv)
+    if argv is None:
+        argv = sys.argv[1:]
+        if not argv and 'WORLD_SIZE' in os.environ and 'ADI_BENCH_ARGV' in os.environ:
+            argv = json.loads(os.environ['ADI_BENCH_ARGV'])      # a rank started by launch_self (see there)
+    argv = list(argv)
     a = parse(argv)
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # started plainly: this process stays off the GPU and starts the ranks as fresh children
@@ -340,20 +444,28 @@ def main(argv=None):
     rehearse = a.rehearse_world if (a.rehearse_world > 1 and world == 1 and a.gpus == 1) else 0
     force_dist = a.force_dist and world == 1
     multi = world > 1 or rehearse > 1 or force_dist   # the slab code path
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    staged = a.transport == 'gloo-staged' and world > 1      # TEST transport: every rank on cuda:0, payloads through the host
+    local_rank = 0 if staged else int(os.environ.get('LOCAL_RANK', '0'))
     assert world == a.gpus, 'WORLD_SIZE (%d) != --gpus (%d)' % (world, a.gpus)
     need_gpu(rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    import datetime
     import torch.distributed as dist
     if world > 1 or force_dist:
         from adi_thermal_fields_amd.dist_slab import rccl_env_defaults
         rccl_env_defaults()                      # dmabuf IPC; RCCL kernels on a hardware queue of their own
+        # a collective that hangs (ranks in different interface forms, a lost peer) must end inside the driver's 600 s with a
+        # stack trace from the process group's watchdog, not as "killed at limit, wrote nothing"
+        tmo = datetime.timedelta(seconds=a.pg_timeout)
         if force_dist:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
-            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, timeout=tmo)
+        elif staged:
+            dist.init_process_group('gloo', timeout=tmo)
         else:
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group('nccl', device_id=dev, timeout=tmo)
+    col = Collect(dist, world > 1 or force_dist, staged, dev)
 
     import adi_thermal_fields_amd.adi3d_hip_coeff as adi
     from adi_thermal_fields_amd import _lib
@@ -392,16 +504,33 @@ def main(argv=None):
         variant = packs[0].variant
     else:
         from adi_thermal_fields_amd import dist_slab
-        comm = None
-        if rehearse:      # a middle rank of `rehearse`: loopback copies, or (--force-dist) RCCL send/recv to itself
-            comm = (dist_slab.SelfLoopDistComm if force_dist else dist_slab.LoopbackComm)(rehearse, rehearse // 2)
-        stepper = dist_slab.SlabStepper.from_local(T.t, mask, dx, mat, prm, Tinf, robin_h=500.0, comm=comm)
+
+        def make_comm():
+            if rehearse:      # a middle rank of `rehearse`: loopback copies, or (--force-dist) RCCL send/recv to itself
+                return (dist_slab.SelfLoopDistComm if force_dist else dist_slab.LoopbackComm)(rehearse, rehearse // 2)
+            return dist_slab.HostStagedDistComm() if staged else dist_slab.TorchDistComm()
+        # Before anything is timed: does this job's decomposition reproduce the one-domain result?  (1) the n^3 grid cut over
+        # the ranks (BASELINE.json configs[2]; the strong-scaling workload itself); (2) with weak scaling also this job's own slab
+        # thickness -- n planes per rank, hence the interface form of the timed loop -- on a grid of reduced lateral extent
+        # (W*n x 128 x 128), which rank 0 can step on one domain in milliseconds.
+        parity_1d = None
+        if world > 1:
+            from adi_thermal_fields_amd.dist_slab import split_planes as _split
+            parity_1d = parity_vs_one_domain(a, adi, dist_slab, dist, world, rank, mat, prm, dx, Tinf, make_comm, staged,
+                                             _split(n, world), n, n, '%d^3 cut into slabs over the %d ranks (strong split)' % (n, world))
+            if a.scaling != 'strong':
+                lat = min(n, 128)
+                p2 = parity_vs_one_domain(a, adi, dist_slab, dist, world, rank, mat, prm, dx, Tinf, make_comm, staged,
+                                          [n] * world, lat, lat, "the timed job's own slab thickness (%d planes per rank, weak "
+                                          'scaling) on a grid of reduced lateral extent' % n)
+                if parity_1d is not None:
+                    parity_1d = dict(parity_1d, weak_form=p2)
+        stepper = dist_slab.SlabStepper.from_local(T.t, mask, dx, mat, prm, Tinf, robin_h=500.0, comm=make_comm())
         variant = stepper.variant
         overlap_err, overlap_on = stepper.self_check(T)     # pipeline on the second stream vs plain ordering
 
     def sync():
-        if world > 1 or force_dist:
-            dist.barrier()
+        col.barrier()
         torch.cuda.synchronize()
 
     kw = dict(prefetch_halo=True) if multi else {}     # the loop feeds every step's output to the next unmodified
@@ -420,10 +549,7 @@ def main(argv=None):
         T = stepper.step(T, events=ev[s], **kw)     # HIP events on the launch stream between the stage kernels
     sync()
     t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1 or force_dist:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = elapsed.item()
+    elapsed = col.max(t1 - t0)
     assert bool(torch.isfinite(T.t).all().item())
 
     stage_ms = np.array([[ev[s][i].elapsed_time(ev[s][i + 1]) for i in range(nst)] for s in range(a.steps)])
@@ -443,11 +569,8 @@ def main(argv=None):
     total_cells = float(N)
     if world > 1 or force_dist:
         comm = stepper.comm
-        mine = torch.tensor(list(mean_ms) + [float(getattr(comm, 'bytes_sent', 0)), float(getattr(comm, 'n_exchanges', 0)),
-                                             float(t1 - t0), float(N)], dtype=torch.float64, device=dev)
-        allr = torch.empty(dist.get_world_size() * mine.numel(), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allr, mine)
-        allr = allr.view(dist.get_world_size(), -1).cpu().numpy()
+        allr = col.gather_rows(list(mean_ms) + [float(getattr(comm, 'bytes_sent', 0)), float(getattr(comm, 'n_exchanges', 0)),
+                                                float(t1 - t0), float(N)])
         total_cells = float(allr[:, nst + 3].sum())
         nsteps_counted = a.steps + max(a.warmup, 1) + 2            # the counters run from construction (incl. self-check)
         ranks_info = dict(world_size_from_process_group=dist.get_world_size(), backend=dist.get_backend(),
@@ -456,6 +579,8 @@ def main(argv=None):
                           cells_per_rank=[int(v) for v in allr[:, nst + 3]],
                           mbytes_sent_per_rank_total=[round(float(v) / 1e6, 2) for v in allr[:, nst]],
                           exchanges_per_rank_total=[int(v) for v in allr[:, nst + 1]],
+                          transport=('gloo-staged (TEST transport: every rank on cuda:0, payloads through pinned host memory; '
+                                     'not a multi-GPU measurement)' if staged else 'nccl (RCCL)'),
                           note='byte / exchange counters cover %d steps (warm-up, self-check and timed loop)' % nsteps_counted)
     if rank != 0:
         if world > 1:
@@ -521,6 +646,7 @@ def main(argv=None):
                       unit='GB/s', frac=kernels[dom]['frac'], traffic=traffic),
         kernels=kernels,
         **({'ranks': ranks_info} if ranks_info is not None else {}),
+        **({'parity_vs_one_domain': parity_1d} if (multi and world > 1) else {}),
     )
     if xs is not None:
         line['general_pack_sweeps_42B'] = xs

@@ -57,3 +57,25 @@ def test_curved_solid_and_cylindrical_lines():
     assert 'ellipsoid' in d['config']['workload']
     d = _bench('--config', 'cyl', '--steps', '4', '--warmup', '2', '--no-cpu')
     assert d['metric'].startswith('adi_cyl') and set(d['kernels']) == {'sweep_r', 'sweep_phi', 'sweep_z_contig'}
+
+
+@pytest.mark.parametrize('scaling', ['weak', 'strong'])
+def test_two_real_ranks_line_proves_itself_against_one_domain(scaling):
+    """`bench.py --gpus 2` started plainly: the parent starts two ranks (separate processes), here on the one GPU of the box
+    over the gloo-staged test transport.  The line of an N > 1 run must carry `parity_vs_one_domain` -- 3 steps of the n^3 grid
+    cut over the ranks against the same steps on one domain, <= 1e-12 -- and, with weak scaling, the
+    same for the timed job's own slab thickness; plus the `ranks` record."""
+    d = _bench('--gpus', '2', '--n', '128', '--steps', '3', '--warmup', '2', '--no-cpu', '--transport', 'gloo-staged',
+               '--scaling', scaling)
+    assert d['n_gpus'] == 2 and d['scaling'] == scaling
+    p = d['parity_vs_one_domain']
+    assert p['ok'] is True and p['rel_linf'] <= 1e-12 and p['bar'] == 1e-12 and p['steps'] == 3 and p['forms_agree']
+    assert p['grid'] == '128x128x128' and p['planes_per_rank'] == [64, 64] and p['form'] is not None
+    if scaling == 'weak':
+        w = p['weak_form']
+        assert w['ok'] is True and w['rel_linf'] <= 1e-12 and w['planes_per_rank'] == [128, 128] and w['grid'] == '256x128x128'
+    else:
+        assert 'weak_form' not in p
+    r = d['ranks']
+    assert r['world_size_from_process_group'] == 2 and 'gloo-staged' in r['transport'] and len(r['loop_seconds_per_rank']) == 2
+    assert d['comm_overlap']['selfcheck_rel_diff'] <= 1e-12

@@ -51,6 +51,16 @@ def test_launcher_timeout_kills_its_own_process_group():
     assert time.time() - t0 < 60
 
 
+def test_timeouts_stay_inside_the_drivers_limit():
+    """the driver kills `bench.py` at 600 s: the launcher's own limit and the process group's collective timeout must fire
+    before that, so that a hang ends with the tail of the ranks' stderr / a watchdog stack trace instead of nothing"""
+    a = _bench().parse([])
+    assert a.launch_timeout <= 480.0 and a.pg_timeout <= 120.0
+    assert a.launch_timeout + 60.0 < 600.0 and a.pg_timeout < a.launch_timeout
+    calls = [ln for ln in open(os.path.join(ROOT, 'bench.py')) if 'init_process_group(' in ln]
+    assert len(calls) >= 4 and all('timeout=' in ln for ln in calls), calls
+
+
 def test_launcher_clears_inherited_rank_environment():
     """a parent that itself sits inside a torchrun job must not leak its RANK / WORLD_SIZE into the children"""
     os.environ['WORLD_SIZE'] = '7'

@@ -574,6 +574,29 @@ def test_curved_solid_over_the_range_of_time_steps(hip, cfl):
     assert rel_linf(got, want) <= TOL, (cfl, rel_linf(got, want))
 
 
+@pytest.mark.parametrize('cfl', [1e-11, 1e-10, 4e-10, 1.9e-9, 3e-9])
+@pytest.mark.parametrize('shape', [(32, 512, 48), (32, 480, 48), (512, 16, 48)])
+def test_tiny_time_steps_on_long_lines_crossing_a_curved_surface(hip, shape, cfl):
+    """theta*gamma between 5e-12 and 1.5e-9 on 480 / 512-row lines (30 / 32 rows per lane in the strided FAST kernels along
+    axis 1, 16 in the fused one along axis 0) that cross the surface of an ellipsoid: the band in which mixed_condense's
+    growing recurrence, (2 + 1/tg)^(rows-2), overflowed fp64 with round 3's gate of 1e-12 (inf / inf = NaN).  Below
+    kMixedMinTg = 1e-9 the GENERAL kernels take the sweep; just above it the recurrence runs at its largest growth."""
+    from oracle import adi_oracle as orc
+    g = np.meshgrid(*[(np.arange(n) + 0.5) / n - 0.5 for n in shape], indexing='ij')
+    mask = ((g[0] / 0.47) ** 2 + (g[1] / 0.49) ** 2 + (g[2] / 0.48) ** 2 <= 1.0)
+    rng = np.random.default_rng(int(cfl * 1e12) + shape[0])
+    dx = 1e-3
+    alpha = 54.0 / (7800.0 * 490.0)
+    c = dict(shape=shape, dx=dx, mat=dict(rho=7800.0, cp=490.0, k=54.0), mask=mask, T0=rng.uniform(20.0, 1500.0, shape),
+             dir_mask=None, dir_value=None, neumann=None, robin_h=350.0, Tinf=20.0, theta=0.5,
+             dt=cfl * dx * dx / alpha, nsteps=2, births=None)
+    got = run_cart_case(hip, c)['T_final']
+    want = run_cart_case(orc, c)['T_final']
+    assert np.isfinite(got).all()
+    assert np.array_equal(got[~mask], want[~mask])
+    assert rel_linf(got, want) <= TOL, (cfl, rel_linf(got, want))
+
+
 @pytest.mark.parametrize('shape,axis', [((256, 64, 48), 2), ((256, 48, 64), 1), ((64, 256, 48), 0), ((48, 64, 256), 0),
                                         ((96, 96, 96), 2), ((512, 32, 32), 1)])
 @pytest.mark.parametrize('bc', ['lean', 'neumann'])
