@@ -72,8 +72,7 @@ static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t 
                        long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
                        const double *d_xlo, const double *d_xhi, void *d_work, size_t work_bytes, void *stream,
                        const Fuse *fz, const double *fcs, const double *c_lo = nullptr, const double *c_hi = nullptr,
-                       const double *c_w = nullptr, const double *c_wl = nullptr, const double *c_wh = nullptr, long c_ps = 0,
-                       int c_np = 0)
+                       const double *c_w = nullptr)
 {
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep: bad axis %d", axis);
     bool has_dir, has_q;
@@ -100,13 +99,7 @@ static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t 
         // deferred interface correction (adi_sweep_corrected): the strided kernels of memory axis 1 add it to what they load
         ADI_REQUIRE(axis == 1 && fz == nullptr && !d_xlo && !d_xhi, "adi_sweep_corrected: axis 1 sweeps only");
         ADI_REQUIRE((long)ny * nz * 8 < 0x7fffffffL, "adi_sweep_corrected: plane of %ld cells is too large", (long)ny * nz);
-        ADI_REQUIRE((c_wl == nullptr && c_wh == nullptr) || (c_ps >= (long)ny * nz && c_np >= 1 && c_np <= nx),
-                    "adi_sweep_corrected: per-cell weights need weight_plane_stride >= ny*nz and 1 <= weight_nplanes <= nx");
-        ADI_REQUIRE((c_wl == nullptr && c_wh == nullptr) ||
-                    ((c_lo != nullptr) == (c_wl != nullptr) && (c_hi != nullptr) == (c_wh != nullptr)),
-                    "adi_sweep_corrected: per-cell weights go with every interface plane that is present");
         s.c_lo = c_lo; s.c_hi = c_hi; s.c_w = c_w; s.c_n = nx; s.c_bytes = (unsigned)((long)ny * nz * 8);
-        s.c_wl = c_wl; s.c_wh = c_wh; s.c_ps = c_ps; s.c_np = c_np;
     }
     hipStream_t st = as_stream(stream);
     SweepArgs a;
@@ -147,14 +140,13 @@ int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags,
 int adi_sweep_corrected(int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
                         const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
                         long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
-                        const double *d_ulo, const double *d_uhi, const double *d_w, const double *d_wlo, const double *d_whi,
-                        long weight_plane_stride, int weight_nplanes, const double *h_face_consts, void *d_work,
+                        const double *d_ulo, const double *d_uhi, const double *d_w, const double *h_face_consts, void *d_work,
                         size_t work_bytes, void *stream)
 {
     ADI_REQUIRE(d_w != nullptr || (d_ulo == nullptr && d_uhi == nullptr), "adi_sweep_corrected: interface values without weights");
     return sweep_entry(1, variant, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
                        sparse, theta, gam, dt, Tinf, d_out, nullptr, nullptr, d_work, work_bytes, stream, nullptr,
-                       h_face_consts, d_ulo, d_uhi, d_w, d_wlo, d_whi, weight_plane_stride, weight_nplanes);
+                       h_face_consts, d_ulo, d_uhi, d_w);
 }
 
 static Fuse make_fuse(int nx, int ny, int nz, long plane_stride, double dx, double dt, double kappa, double theta,

@@ -77,12 +77,8 @@ struct SweepScal {
     const double *c_lo = nullptr, *c_hi = nullptr, *c_w = nullptr;
     int c_n = 0;
     unsigned c_bytes = 0;   // bytes of a correction plane (the range of the buffer descriptors over c_lo / c_hi)
-    // Lines that are not uniform (adi_sweep_corrected with per-cell weights, ABI v17): the weight of (plane i, cell) is
-    // c_wl[i * c_ps + cell] (resp. c_wh[(c_n - 1 - i) * c_ps + cell]) on the first c_np planes from each end -- c_w holds 1
-    // there and 0 beyond (nothing is loaded) -- instead of the scalar c_w[i]; c_lo / c_hi stay the two interface planes.
-    const double *c_wl = nullptr, *c_wh = nullptr;
-    int c_np = 0;           // (plane indices are clamped to it: an address formed for a plane without weights stays inside)
-    long c_ps = 0;
+    // (Lines that are not uniform: their own weights are applied in memory by adi_deferred_lines_apply before this sweep, and
+    // c_lo / c_hi carry zeros on them -- ABI v18; v17 streamed per-cell weight planes through this kernel.)
     // Packs built from per-face SCALARS (h_face_consts of the sweep entry points; only with `sparse`): the Robin coefficient /
     // Neumann flux of a cell exposed along the sweep axis is  (0 + [minus neighbour missing] fc[0]) + [plus neighbour missing]
     // fc[1]  (flux: fc[2], fc[3]) -- the accumulation order of precompute_coeff_packs_unified (adi3d_numba_coeff.py:93-114),
@@ -489,44 +485,25 @@ template <int M>
 __device__ __forceinline__ void corr_apply(const SweepScal &s, double2 w, long to, unsigned off8, unsigned st8, double (&d)[M],
                                            bool inside)
 {
+    (void)to;
     if (w.x != 0.0) {
         const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc((void *)s.c_lo, 0, (int)s.c_bytes, 0x00020000);
-        if (s.c_wl != nullptr) {           // per-cell weights: a plane of this slab plane's own, streamed once
-            const long pl = to < s.c_np ? to : s.c_np - 1;
-            const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void *)(s.c_wl + pl * s.c_ps), 0, (int)s.c_bytes, 0x00020000);
+        if (inside) {                  // every row of the tile lies inside the plane: scalar row offsets (0.02 ms at 512^3)
 #pragma unroll
-            for (int r = 0; r < M; ++r) {
-                const unsigned vo = inside ? off8 : off8 + (unsigned)r * st8, so = inside ? (unsigned)r * st8 : 0u;
-                d[r] = __builtin_fma(buf_load_f64(rW, vo, so), buf_load_f64(rL, vo, so), d[r]);
-            }
+            for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.x, buf_load_f64(rL, off8, (unsigned)r * st8), d[r]);
         } else {
-            if (inside) {                  // every row of the tile lies inside the plane: scalar row offsets (0.02 ms at 512^3)
 #pragma unroll
-                for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.x, buf_load_f64(rL, off8, (unsigned)r * st8), d[r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.x, buf_load_f64(rL, off8 + (unsigned)r * st8, 0u), d[r]);
-            }
+            for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.x, buf_load_f64(rL, off8 + (unsigned)r * st8, 0u), d[r]);
         }
     }
     if (w.y != 0.0) {
         const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void *)s.c_hi, 0, (int)s.c_bytes, 0x00020000);
-        if (s.c_wh != nullptr) {
-            const long q = s.c_n - 1 - to, ph = q < s.c_np ? q : s.c_np - 1;
-            const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void *)(s.c_wh + ph * s.c_ps), 0, (int)s.c_bytes, 0x00020000);
+        if (inside) {
 #pragma unroll
-            for (int r = 0; r < M; ++r) {
-                const unsigned vo = inside ? off8 : off8 + (unsigned)r * st8, so = inside ? (unsigned)r * st8 : 0u;
-                d[r] = __builtin_fma(buf_load_f64(rW, vo, so), buf_load_f64(rH, vo, so), d[r]);
-            }
+            for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.y, buf_load_f64(rH, off8, (unsigned)r * st8), d[r]);
         } else {
-            if (inside) {
 #pragma unroll
-                for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.y, buf_load_f64(rH, off8, (unsigned)r * st8), d[r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.y, buf_load_f64(rH, off8 + (unsigned)r * st8, 0u), d[r]);
-            }
+            for (int r = 0; r < M; ++r) d[r] = __builtin_fma(w.y, buf_load_f64(rH, off8 + (unsigned)r * st8, 0u), d[r]);
         }
     }
 }

@@ -499,7 +499,8 @@ __global__ __launch_bounds__(256) void k_interface_deferred_lines(
     const double *__restrict__ first, const double *__restrict__ last, const double *__restrict__ prev_last,
     const double *__restrict__ next_first, const double *__restrict__ om_lo_own, const double *__restrict__ om_hi_prev,
     const double *__restrict__ om_hi_own, const double *__restrict__ om_lo_next, long nlines, double *__restrict__ ulo,
-    double *__restrict__ uhi)
+    double *__restrict__ uhi, const uint8_t *__restrict__ uni_lo, const uint8_t *__restrict__ uni_hi,
+    double *__restrict__ ulo_uni, double *__restrict__ uhi_uni)
 {
     const long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nlines) return;
@@ -515,6 +516,29 @@ __global__ __launch_bounds__(256) void k_interface_deferred_lines(
     }
     ulo[l] = lo;
     uhi[l] = hi;
+    // the same values on the lines whose rows within reach of the interface are uniform (they take the scalar weights inside
+    // the axis-1 sweep); the others get their own weights from k_deferred_lines_apply, or none (lines outside the mask)
+    if (ulo_uni != nullptr) ulo_uni[l] = (uni_lo != nullptr && uni_lo[l] != 0) ? lo : 0.0;
+    if (uhi_uni != nullptr) uhi_uni[l] = (uni_hi != nullptr && uni_hi[l] != 0) ? hi : 0.0;
+}
+
+// x[i][cell[q]] += wc[r][q] * u[cell[q]]: the rank-one update of the flagged lines of one side of the slab (the lines that
+// cross a void, the surface or a Dirichlet cell within reach of the interface).  Thread = one flagged line, blockIdx.y strides
+// the K rows; consecutive q are mostly consecutive cells (runs along the contiguous axis), the compact weights are read
+// coalesced.  The same fma as corr_apply: a line gives the same bits whichever way its correction is applied.
+__global__ __launch_bounds__(256) void k_deferred_lines_apply(double *__restrict__ x, int nx, long sx, const int *__restrict__ cells,
+                                                              long nflag, const double *__restrict__ wc, int K,
+                                                              const double *__restrict__ u, int from_hi)
+{
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nflag) return;
+    const long cell = cells[q];
+    const double uu = u[cell];
+    for (int r = blockIdx.y; r < K; r += gridDim.y) {
+        const long i = from_hi ? (long)(nx - 1 - r) : (long)r;
+        double *p = x + i * sx + cell;
+        *p = __builtin_fma(wc[(long)r * nflag + q], uu, *p);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -645,14 +669,29 @@ int adi_interface_deferred(const double *d_first, const double *d_last, const do
 int adi_interface_deferred_lines(const double *d_first, const double *d_last, const double *d_prev_last,
                                  const double *d_next_first, const double *d_om_lo_own, const double *d_om_hi_prev,
                                  const double *d_om_hi_own, const double *d_om_lo_next, long nlines, double *d_ulo,
-                                 double *d_uhi, void *stream)
+                                 double *d_uhi, const uint8_t *d_uni_lo, const uint8_t *d_uni_hi, double *d_ulo_uni,
+                                 double *d_uhi_uni, void *stream)
 {
     ADI_REQUIRE(d_first && d_last && d_ulo && d_uhi && nlines > 0, "adi_interface_deferred_lines: bad argument");
     ADI_REQUIRE(!d_prev_last || (d_om_lo_own && d_om_hi_prev), "adi_interface_deferred_lines: lower boundary without its weights");
     ADI_REQUIRE(!d_next_first || (d_om_hi_own && d_om_lo_next), "adi_interface_deferred_lines: upper boundary without its weights");
     hipLaunchKernelGGL(k_interface_deferred_lines, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, as_stream(stream),
                        d_first, d_last, d_prev_last, d_next_first, d_om_lo_own, d_om_hi_prev, d_om_hi_own, d_om_lo_next,
-                       nlines, d_ulo, d_uhi);
+                       nlines, d_ulo, d_uhi, d_uni_lo, d_uni_hi, d_ulo_uni, d_uhi_uni);
+    ADI_CHECK_LAUNCH();
+    return ADI_OK;
+}
+
+int adi_deferred_lines_apply(double *d_x, int nx, long plane_stride, long plane_cells, const int *d_cells, long nflag,
+                             const double *d_wc, int K, const double *d_u, int from_high_end, void *stream)
+{
+    ADI_REQUIRE(d_x && d_u && nx > 0 && plane_cells > 0 && plane_stride >= plane_cells && K >= 0 && K <= nx && nflag >= 0,
+                "adi_deferred_lines_apply: bad argument");
+    if (nflag == 0 || K == 0) return ADI_OK;
+    ADI_REQUIRE(d_cells && d_wc, "adi_deferred_lines_apply: flagged lines without their cells / weights");
+    const unsigned gy = (unsigned)(K < 64 ? K : 64);
+    hipLaunchKernelGGL(k_deferred_lines_apply, dim3((unsigned)((nflag + 255) / 256), gy), dim3(256), 0, as_stream(stream), d_x, nx,
+                       plane_stride, d_cells, nflag, d_wc, K, d_u, from_high_end);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }

@@ -142,6 +142,15 @@ __device__ __forceinline__ unsigned packed_byte(const unsigned (&w)[M / 4], int 
 // scalar registers, ONE 32-bit per-thread offset for every load and store -- the flat-addressed form above keeps a 64-bit
 // pointer per row alive from the first load to the last store (32 VGPRs at 8 rows), which is what pushed the 42 B/cell
 // kernel over its 128-VGPR budget into scratch.
+#ifndef ADI_GEN_PACK_AUX
+#define ADI_GEN_PACK_AUX 0   // cache policy of the dense pack-array loads of the buffer-addressed GENERAL loader (2 = nt; A/B knob)
+#endif
+template <int AUX>
+__device__ __forceinline__ double buf_load_f64_aux(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
 template <int M, bool HAS_DIR, bool HAS_Q, int FCM = 0>
 __device__ __forceinline__ void load_segment_raw_buf(
     const double *__restrict__ in_t, const uint8_t *__restrict__ flags_t, const double *__restrict__ coeff_t,
@@ -205,9 +214,9 @@ __device__ __forceinline__ void load_segment_raw_buf(
 #pragma unroll
         for (int r = 0; r < M; ++r) {
             if (HAS_DIR && !packed) R.or_dir(r, __builtin_amdgcn_raw_buffer_load_b8(rM, voff, (unsigned)r * st, 0) != 0);
-            R.vco[r] = buf_load_f64(rC, vb, (unsigned)r * st8);
-            R.vq[r] = HAS_Q ? buf_load_f64(rQ, vb, (unsigned)r * st8) : 0.0;
-            R.vdv[r] = HAS_DIR ? buf_load_f64(rV, vb, (unsigned)r * st8) : 0.0;
+            R.vco[r] = buf_load_f64_aux<ADI_GEN_PACK_AUX>(rC, vb, (unsigned)r * st8);
+            R.vq[r] = HAS_Q ? buf_load_f64_aux<ADI_GEN_PACK_AUX>(rQ, vb, (unsigned)r * st8) : 0.0;
+            R.vdv[r] = HAS_DIR ? buf_load_f64_aux<ADI_GEN_PACK_AUX>(rV, vb, (unsigned)r * st8) : 0.0;
         }
     } else {
 #pragma unroll

@@ -122,8 +122,11 @@ __device__ __forceinline__ void strided_tile_general(
 // unit queue).  Two instantiations, not a run-time branch: with both bodies in one kernel the values the loop keeps alive
 // across its iterations were spilled (16 - 20 B of scratch per lane in the 42 B/cell kernel), and scratch set up for the
 // direct form as well.
+#ifndef ADI_GEN_OCC
+#define ADI_GEN_OCC 1     // waves per SIMD the direct 8-row buffer-addressed build is compiled for (A/B: scripts/ab_build.sh)
+#endif
 template <int M, bool HAS_DIR, bool HAS_Q, bool FUSE = false, bool WHOLE = false, int FCM = 0, bool CORR = true, bool QUEUED = false>
-__global__ __launch_bounds__(M <= 8 ? 1024 : 512) void k_sweep_strided(
+__global__ __launch_bounds__(M <= 8 ? 1024 : 512, (M == 8 && WHOLE && !QUEUED) ? ADI_GEN_OCC : 1) void k_sweep_strided(
     const double *__restrict__ in, const uint8_t *__restrict__ flags, const double *__restrict__ coeff,
     const uint8_t *__restrict__ dmask, const double *__restrict__ dval, const double *__restrict__ qf,
     double *__restrict__ out, LineGeom g, int Lp, int LINES, int tiles_inner, long ntiles,

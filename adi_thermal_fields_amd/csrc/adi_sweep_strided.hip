@@ -29,11 +29,9 @@ __global__ __launch_bounds__(256) void k_sweep_generic(
         const unsigned f = flags[p];
         double a, b, c, d;
         double vin = in[p];
-        const long cell = (long)r * g.stride + kc * inner_stride, qo = s.c_n - 1 - o;
-        if (cw.x != 0.0)
-            vin = __builtin_fma(s.c_wl != nullptr ? s.c_wl[(o < s.c_np ? o : s.c_np - 1) * s.c_ps + cell] : cw.x, s.c_lo[cell], vin);
-        if (cw.y != 0.0)
-            vin = __builtin_fma(s.c_wh != nullptr ? s.c_wh[(qo < s.c_np ? qo : s.c_np - 1) * s.c_ps + cell] : cw.y, s.c_hi[cell], vin);
+        const long cell = (long)r * g.stride + kc * inner_stride;
+        if (cw.x != 0.0) vin = __builtin_fma(cw.x, s.c_lo[cell], vin);
+        if (cw.y != 0.0) vin = __builtin_fma(cw.y, s.c_hi[cell], vin);
         assemble_row<HAS_DIR, HAS_Q>(f & 1u, (f >> g.lbit) & 1u, (f >> (g.lbit + 1)) & 1u, HAS_DIR && dmask[p] != 0, vin,
                                      coeff[p], HAS_DIR ? dval[p] : 0.0, HAS_Q ? qf[p] : 0.0, s, a, b, c, d);
         if (r == 0) { if (xlo != nullptr) d -= a * xlo[lid]; a = 0.0; }

@@ -494,19 +494,15 @@ class HipEngine:
         self.check(self.lib.adi_interface_deferred(h._p(first), h._p(last), h._p(prev_last), h._p(next_first), omega,
                                                    nlines, h._p(ulo), h._p(uhi), self._sp()))
 
-    def sweep_corrected(self, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, ulo, uhi, w_corr, wlo=None, whi=None):
-        """axis-1 sweep of t_in + w[i] * ulo + w[n-1-i] * uhi; with wlo / whi ((K, ny, nz) dense, the planes of whi counted
-        from the far end) the weights are per cell and w says which planes have them"""
+    def sweep_corrected(self, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, ulo, uhi, w_corr):
+        """axis-1 sweep of t_in + w[i] * ulo + w[n-1-i] * uhi (the correction is added to what the sweep loads)"""
         h = self.hip
         w = self._workspace(Li)
         key, bit = self._promise('sweep', 1, variant, Li, flags, pack)
         a = list(self._args(1, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf))
         a[12] |= bit
-        wp = wlo if wlo is not None else whi
-        ps, npl = (int(wp.stride(0)), int(wp.shape[0])) if wp is not None else (0, 0)
-        assert wlo is None or whi is None or (wlo.stride(0) == whi.stride(0) and wlo.shape[0] == whi.shape[0])
-        self.check(self.lib.adi_sweep_corrected(*a[1:], h._p(t_out), h._p(ulo), h._p(uhi), h._p(w_corr), h._p(wlo), h._p(whi),
-                                                ps, npl, self._fc(pack), h._p(w), w.numel(), self._sp()))
+        self.check(self.lib.adi_sweep_corrected(*a[1:], h._p(t_out), h._p(ulo), h._p(uhi), h._p(w_corr), self._fc(pack),
+                                                h._p(w), w.numel(), self._sp()))
         self._learn(key, w)
 
     # the deferred form for lines that are not uniform (ABI v17): per-line homogeneous solutions
@@ -530,11 +526,23 @@ class HipEngine:
                                       h._p(w), w.numel(), self._sp()))
         return out
 
-    def interface_deferred_lines(self, first, last, prev_last, next_first, om, nlines, ulo, uhi):
+    def interface_deferred_lines(self, first, last, prev_last, next_first, om, nlines, ulo, uhi, uni_lo=None, uni_hi=None,
+                                 ulo_uni=None, uhi_uni=None):
+        """ulo / uhi: the interface values of every line; ulo_uni / uhi_uni: the same on the lines uni_lo / uni_hi mark
+        (one byte per line) and 0 elsewhere -- what the scalar weights of adi_sweep_corrected multiply"""
         h = self.hip
         self.check(self.lib.adi_interface_deferred_lines(h._p(first), h._p(last), h._p(prev_last), h._p(next_first),
                                                          h._p(om.get('lo_own')), h._p(om.get('hi_prev')), h._p(om.get('hi_own')),
-                                                         h._p(om.get('lo_next')), nlines, h._p(ulo), h._p(uhi), self._sp()))
+                                                         h._p(om.get('lo_next')), nlines, h._p(ulo), h._p(uhi), h._p(uni_lo),
+                                                         h._p(uni_hi), h._p(ulo_uni), h._p(uhi_uni), self._sp()))
+
+    def deferred_lines_apply(self, Li, x, cells, wc, u, from_high_end):
+        """x[i][cells[q]] += wc[r][q] * u[cells[q]], i = r or nx-1-r: the flagged lines of one side get their own weights"""
+        h = self.hip
+        if cells.numel() == 0:
+            return
+        self.check(self.lib.adi_deferred_lines_apply(h._p(x), Li.nx, Li.sx, Li.ny * Li.nz, h._p(cells), cells.numel(), h._p(wc),
+                                                     int(wc.shape[0]), h._p(u), 1 if from_high_end else 0, self._sp()))
 
 
     def condense0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, cond, r0_out=None):
@@ -643,6 +651,7 @@ class SlabStepper:
         self._allow_deferred = True                # False: never the deferred form (zero-boundary solve + correction on load)
         self._allow_deferred_exact = True          # False: thin slabs (no decay) keep the two-pass all-gather form
         self._allow_deferred_lines = True          # False: lines that are not uniform keep the two-pass forms
+        self._deferred_lines_cost_ratio = 1.0      # ... and so do slabs whose flagged lines cost more than this x pass A (tests: inf)
         self._plan_steps = None                    # steps taken under the current axis-0 plan (None: no plan yet)
         self._send_g_only = True                   # False: every step exchanges the matrix parts of the interface too
         self._comm_stream, self._use_streams = None, False
@@ -887,7 +896,7 @@ class SlabStepper:
         prm = self.params
         key = (float(prm.dt), float(prm.theta), self._mask_version, self._force_exact, self._no_overlap,
                self._allow_fused, self._allow_window, self._keep_r0, self._allow_dots, self._allow_deferred,
-               self._allow_deferred_exact, self._allow_deferred_lines)
+               self._allow_deferred_exact, self._allow_deferred_lines, self._deferred_lines_cost_ratio)
         if self._a0_key == key:
             self._plan_steps += 1
             return self._a0
@@ -1069,21 +1078,46 @@ class SlabStepper:
         first, last = self.rank == 0, self.rank == self.world - 1
         # where to look: the reach of the uniform row's solution plus a margin (a run that ends in a line start reflects);
         # what decides is the check below
-        K = min(n, int(E.deferred_setup(n, prm.theta, gam, self.DECAY_TOL)['reach']) + 8)
-        # ... and where it pays: the axis-1 sweep reads 2 K weight planes, the two-pass forms the slab a second time -- at
-        # K = 399 of 512 planes (cfl 200) the two were level (2.26 against 2.19 - 2.46 ms from box to box), at K = 183 1.97 : 2.47
-        ok = n >= 2 and K < n and 5 * K <= 3 * n
-        om, Wlo, Whi = {}, None, None
+        dfr = E.deferred_setup(n, prm.theta, gam, self.DECAY_TOL)
+        K = min(n, int(dfr['reach']) + 8)
+        ok = n >= 2 and K < n
+        om, sides = {}, {}
+        dm = pk[1]                                  # Dirichlet mask of the slab (None: no Dirichlet cells)
+
+        def sort_lines(Wr, fr, dr):
+            """(uniform marks [nlines] uint8, cells of the flagged lines int32, their weights [K][nflag]) of one side.  Wr, fr,
+            dr: the K planes of the homogeneous solution, the flags and the Dirichlet mask within reach of the interface, counted
+            from it.  A line is uniform when every one of them is a solid interior row (bit 0 and both sharded-axis neighbour
+            bits of its flags byte) without a Dirichlet cell -- its homogeneous solution is then the scalar w[i] there, up to
+            the decay tolerance --, off when none is in the mask (identity rows: weight 0), flagged otherwise."""
+            uni = ((fr & 7) == 7).all(dim=0)
+            if dr is not None:
+                uni &= ~(dr != 0).any(dim=0)
+            off = ((fr & 1) == 0).all(dim=0)
+            cells = (~(uni | off)).reshape(-1).nonzero().reshape(-1)
+            wc = Wr.reshape(Wr.shape[0], -1).index_select(1, cells).contiguous()
+            return uni.reshape(-1).to(torch.uint8).contiguous(), cells.to(torch.int32).contiguous(), wc
+        nflag = 0
         if ok and not first:
             W = E.homogeneous_solution(self.variant, self.Lint, fl, pk, prm.theta, gam, prm.dt, True)
             ok = bool(float(W[K:].abs().max()) <= self.DECAY_TOL)             # NaN compares false
-            Wlo = W[:K].contiguous()
             om['lo_own'] = W[0].clone()
+            if ok:
+                sides['lo'] = sort_lines(W[:K], fl[:K], None if dm is None else dm[:K])
+                nflag += int(sides['lo'][1].numel())
+            del W
         if ok and not last:
             W = E.homogeneous_solution(self.variant, self.Lint, fl, pk, prm.theta, gam, prm.dt, False)
             ok = bool(float(W[:n - K].abs().max()) <= self.DECAY_TOL)
-            Whi = W[n - K:].flip(0).contiguous()                              # plane q belongs to slab plane n-1-q
             om['hi_own'] = W[n - 1].clone()
+            if ok:
+                sides['hi'] = sort_lines(W[n - K:].flip(0), fl[n - K:], None if dm is None else dm[n - K:])   # row r: plane n-1-r
+                nflag += int(sides['hi'][1].numel())
+            del W
+        # ... and where it pays: the sparse pass moves 24 B per flagged line and row within reach (its weight, the value read
+        # and written); what it replaces is pass A of the two-pass forms, 17 B per cell of the 2 K planes of a window or of the
+        # whole slab.  A solid riddled with voids (every line flagged) is left to those; a part with a few cavities is not.
+        ok = ok and 24.0 * nflag * K <= self._deferred_lines_cost_ratio * 17.0 * nl_ * min(2 * K, n)
         flag, allf = E.vec(1), E.vec(self.world)
         flag.fill_(1.0 if ok else 0.0)
         self.comm.all_gather(allf, flag)
@@ -1095,10 +1129,9 @@ class SlabStepper:
         om['lo_next'] = None if last else E.vec(nl_).view(self.ny, self.nz)
         self.comm.exchange_planes(om.get('lo_own', dummy), om.get('hi_own', dummy),
                                   dummy if first else om['hi_prev'], dummy if last else om['lo_next'])
-        w01 = E.vec(n)                     # (zero-filled)
-        w01[:K] = 1.0
-        return dict(mode='deferred_lines', K=K, fused=fused_ok, dots=False, keep_r0=False, chunks=[], om=om, Wlo=Wlo, Whi=Whi,
-                    w01=w01, ulo=E.vec(nl_), uhi=E.vec(nl_), prev_last=E.vec(nl_), next_first=E.vec(nl_))
+        return dict(mode='deferred_lines', K=K, fused=fused_ok, dots=False, keep_r0=False, chunks=[], om=om, dfr=dfr, sides=sides,
+                    nflag=nflag, ulo=E.vec(nl_), uhi=E.vec(nl_), ulo_uni=E.vec(nl_), uhi_uni=E.vec(nl_),
+                    prev_last=E.vec(nl_), next_first=E.vec(nl_))
 
     def _condense_box(self, plan, L, src, p0, p1, j0, j1, cond):
         """pass A on planes [p0, p1), rows [j0, j1) of the slab.  src: the explicit stage's output (interior view) or,
@@ -1327,10 +1360,17 @@ class SlabStepper:
                                           plan['next_first'].view(self.ny, self.nz))
                 first, last = self.rank == 0, self.rank == self.world - 1
                 if plan['mode'] == 'deferred_lines':
-                    # per-line weights (the axis-1 sweep reads them per cell on the K planes at each end)
+                    # the interface values of every line, and the same masked to the lines that are uniform within reach (the
+                    # scalar weights of the axis-1 sweep multiply those); the flagged lines get their own weights here, in memory
+                    sd = plan['sides']
                     E.interface_deferred_lines(Bi[0], Bi[nl - 1], None if first else plan['prev_last'],
                                                None if last else plan['next_first'], plan['om'], self.nlines, plan['ulo'],
-                                               plan['uhi'])
+                                               plan['uhi'], sd['lo'][0] if 'lo' in sd else None, sd['hi'][0] if 'hi' in sd else None,
+                                               plan['ulo_uni'], plan['uhi_uni'])
+                    if 'lo' in sd:
+                        E.deferred_lines_apply(Li, Bi, sd['lo'][1], sd['lo'][2], plan['ulo'], False)
+                    if 'hi' in sd:
+                        E.deferred_lines_apply(Li, Bi, sd['hi'][1], sd['hi'][2], plan['uhi'], True)
                 else:
                     E.interface_deferred(Bi[0], Bi[nl - 1], None if first else plan['prev_last'],
                                          None if last else plan['next_first'], plan['dfr']['omega'], self.nlines, plan['ulo'],
@@ -1400,8 +1440,8 @@ class SlabStepper:
         # 4. local sweeps
         if plan is not None and plan['mode'] == 'deferred_lines':
             E.sweep_corrected(v, Li, Bi, fl, self.packs_int[1], prm.theta, gam, prm.dt, self.Tinf, Ai,
-                              None if self.rank == 0 else plan['ulo'], None if self.rank == self.world - 1 else plan['uhi'],
-                              plan['w01'], plan['Wlo'], plan['Whi'])
+                              None if self.rank == 0 else plan['ulo_uni'], None if self.rank == self.world - 1 else plan['uhi_uni'],
+                              plan['dfr']['w'])
         elif plan is not None and plan['mode'].startswith('deferred'):
             ex_ = plan['mode'] == 'deferred_exact'        # (there the end ranks carry a Sherman-Morrison term on both vectors)
             E.sweep_corrected(v, Li, Bi, fl, self.packs_int[1], prm.theta, gam, prm.dt, self.Tinf, Ai,

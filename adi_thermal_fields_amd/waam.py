@@ -14,7 +14,7 @@ import math
 
 import numpy as np
 
-__all__ = ['synthetic_head_mask', 'plan_layers', 'birth_times', 'run_layer_birth', 'run_single_track',
+__all__ = ['synthetic_head_mask', 'plan_layers', 'birth_times', 'layer_birth_schedule', 'run_layer_birth', 'run_single_track',
            'run_layer_birth_slab', 'run_single_track_slab']
 
 
@@ -59,6 +59,32 @@ def birth_times(mask_full, layers, dx, bead_width, scan_speed, eta_fill=1.0):
     return [float(t) for t in np.cumsum(np.asarray(dur, dtype=np.float64))] if dur else []
 
 
+def layer_birth_schedule(times_birth, times_out):
+    """The clock of the reference's event loop (waam_from_stl_v7_mm.py:515-550) as a stream of actions, in its order:
+         ('advance', seconds)   integrate the field over this interval (the consumer splits it into sub-steps under its
+                                time-step cap and skips it while nothing is active, :524-528)
+         ('birth', layer)       activate layer number `layer` (:487-495) and rebuild the packs (:534)
+         ('frame', t)           an output time has been reached (:540-548)
+    Between two consecutive event times every birth that is due is taken first, each preceded by the time that has passed
+    since the previous action; intervals of at most 1e-15 s are dropped, output times are matched to 1e-12 s -- the
+    reference's tolerances.  One schedule drives the single-domain loop and the per-rank slab loop alike."""
+    nb = len(times_birth)
+    nxt, t_now = 0, 0.0
+    for te in sorted(set(times_out) | set(times_birth)):
+        while nxt < nb and times_birth[nxt] <= te + 1e-15:
+            t_b = times_birth[nxt]
+            if t_b - t_now > 1e-15:
+                yield ('advance', t_b - t_now)
+            t_now = t_b
+            yield ('birth', nxt)
+            nxt += 1
+        if te - t_now > 1e-15:
+            yield ('advance', te - t_now)
+        t_now = te
+        if any(abs(te - to) <= 1e-12 for to in times_out):
+            yield ('frame', te)
+
+
 GRAPH_MIN_NSUB = 16      # segments at least this long run through StagedStepper.run (graph capture costs about a step)
 
 
@@ -101,7 +127,6 @@ def run_layer_birth(backend, mask_full, dx, mat_args, h, Tinf, Ts, theta, cfl, l
                                                       robin_h=robin, robin_Tinf=Tinf)
     packs = None
     nsteps = 0
-    next_birth, t_now = 0, 0.0
 
     def advance(seg):
         nonlocal T, nsteps
@@ -130,48 +155,38 @@ def run_layer_birth(backend, mask_full, dx, mat_args, h, Tinf, Ts, theta, cfl, l
         packs = bpacks.packs
         plane_cells = np.asarray(mask_full).sum(axis=(0, 1)).astype(np.int64)      # newborn cells per plane, host-known
         plane_born = np.zeros(nz, dtype=bool)
-    if not dev_loop:
+    else:
         packs = build_packs()
     n_active = 0
 
-    def host_mask():
-        return d_act.cpu().contiguous().numpy().astype(bool) if dev_loop else mask_act.copy()
+    def birth(ks, ke):
+        nonlocal T, packs, n_active
+        if dev_loop:
+            backend.birth_planes(T, d_act, d_full, grid, ks, ke + 1, Ts)          # :489-493 + mask_act |= born
+            fresh = ~plane_born[ks:ke + 1]
+            n_active += int(plane_cells[ks:ke + 1][fresh].sum())
+            plane_born[ks:ke + 1] = True
+            grid.set_mask_device(d_act, ks - 1 if ks > 0 else 0, min(nz, ke + 2), all_solid=False)   # :494-495
+            packs = bpacks.update(ks - 1, ke + 2)                                 # :534, the planes that changed
+            return
+        born = np.zeros_like(mask_full, dtype=bool)
+        born[:, :, ks:ke + 1] = mask_full[:, :, ks:ke + 1]
+        newborn = born & (~mask_act)
+        if newborn.any():
+            T = _birth(backend, T, grid, newborn, Ts)
+        mask_act[...] = mask_act | born
+        n_active = int(mask_act.sum())
+        grid.mask = mask_act                           # :494-495
+        packs = build_packs()                          # :534
 
-    events = sorted(set(list(times_out) + list(times_birth)))
-    for te in events:
-        while next_birth < len(times_birth) and times_birth[next_birth] <= te + 1e-15:
-            t_b = times_birth[next_birth]
-            seg = max(0.0, t_b - t_now)
-            if seg > 1e-15 and n_active > 0:         # no ADI steps while nothing is active (:524)
-                advance(seg)
-            t_now = t_b
-            ks, ke = layers[next_birth]
-            if dev_loop:
-                backend.birth_planes(T, d_act, d_full, grid, ks, ke + 1, Ts)          # :489-493 + mask_act |= born
-                fresh = ~plane_born[ks:ke + 1]
-                n_active += int(plane_cells[ks:ke + 1][fresh].sum())
-                plane_born[ks:ke + 1] = True
-                grid.set_mask_device(d_act, ks - 1 if ks > 0 else 0, min(nz, ke + 2), all_solid=False)   # :494-495
-                packs = bpacks.update(ks - 1, ke + 2)                                 # :534, the planes that changed
-                next_birth += 1
-                continue
-            else:
-                born = np.zeros_like(mask_full, dtype=bool)
-                born[:, :, ks:ke + 1] = mask_full[:, :, ks:ke + 1]
-                newborn = born & (~mask_act)
-                if newborn.any():
-                    T = _birth(backend, T, grid, newborn, Ts)
-                mask_act |= born
-                n_active = int(mask_act.sum())
-                grid.mask = mask_act                       # :494-495
-            packs = build_packs()                      # :534
-            next_birth += 1
-        seg = max(0.0, te - t_now)
-        if seg > 1e-15 and n_active > 0:
-            advance(seg)
-        t_now = te
-        if on_frame is not None and any(abs(te - to) <= 1e-12 for to in times_out):
-            on_frame(t_now, np.asarray(T), host_mask())
+    for what, arg in layer_birth_schedule(times_birth, times_out):
+        if what == 'advance':
+            if n_active > 0:                           # no ADI steps while nothing is active (:524)
+                advance(arg)
+        elif what == 'birth':
+            birth(*layers[arg])
+        elif on_frame is not None:
+            on_frame(arg, np.asarray(T), d_act.cpu().contiguous().numpy().astype(bool) if dev_loop else mask_act.copy())
     return np.asarray(T), nsteps
 
 
@@ -242,8 +257,8 @@ def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, 
         count = torch.zeros(1, dtype=torch.int64, device=E.device)
         plane_cells = np.asarray(mask_full).sum(axis=(0, 1)).astype(np.int64)
         plane_born = np.zeros(nz, dtype=bool)
-        n_active = 0
-    nsteps, next_birth, t_now = 0, 0, 0.0
+    n_active = 0
+    nsteps = 0
 
     def advance(seg):
         nonlocal T, nsteps
@@ -253,46 +268,41 @@ def run_layer_birth_slab(comm, i0, i1, mask_full, dx, mat, params_cls, h, Tinf, 
             T = st.step(T, prefetch_halo=(s + 1 < nsub))
         nsteps += nsub
 
-    events = sorted(set(list(times_out) + list(times_birth)))
-    for te in events:
-        while next_birth < len(times_birth) and times_birth[next_birth] <= te + 1e-15:
-            t_b = times_birth[next_birth]
-            seg = max(0.0, t_b - t_now)
-            if seg > 1e-15 and (n_active > 0 if dev_loop else mask_act.any()):
-                advance(seg)
-            t_now = t_b
-            ks, ke = layers[next_birth]
-            if dev_loop:
-                if not isinstance(T, torch.Tensor) or T.data_ptr() != dist_slab._interior(st._ext_bufs[st._cur]).data_ptr():
-                    T = st._logical(dist_slab._interior(st._load_state(T)))   # the state buffer itself (nothing stepped yet)
-                E.birth_planes(st.Lint, T, dist_slab._interior(st.d_mask_ext), d_full_int, ks, ke + 1, Ts, count)
-                fresh = ~plane_born[ks:ke + 1]
-                n_active += int(plane_cells[ks:ke + 1][fresh].sum())
-                plane_born[ks:ke + 1] = True
-                st.set_mask_device(ks, ke + 1)
-                next_birth += 1
-                continue
-            born = np.zeros_like(mask_full, dtype=bool)
-            born[:, :, ks:ke + 1] = mask_full[:, :, ks:ke + 1]
-            newborn = (born & (~mask_act))[i0:i1]
-            if newborn.any():
-                if on_device:
-                    T[torch.from_numpy(newborn).to(T.device)] = Ts      # in place (the last sub-step sent no halo ahead)
-                else:
-                    Tl = np.array(st.local_numpy(T))
-                    Tl[newborn] = Ts
-                    T = Tl
-            mask_act |= born
-            st.set_mask(mask_act[i0:i1])
-            next_birth += 1
-        seg = max(0.0, te - t_now)
-        if seg > 1e-15 and (n_active > 0 if dev_loop else mask_act.any()):
-            advance(seg)
-        t_now = te
-        if on_frame is not None and any(abs(te - to) <= 1e-12 for to in times_out):
+    def birth(ks, ke):
+        nonlocal T, n_active
+        if dev_loop:
+            if not isinstance(T, torch.Tensor) or T.data_ptr() != dist_slab._interior(st._ext_bufs[st._cur]).data_ptr():
+                T = st._logical(dist_slab._interior(st._load_state(T)))   # the state buffer itself (nothing stepped yet)
+            E.birth_planes(st.Lint, T, dist_slab._interior(st.d_mask_ext), d_full_int, ks, ke + 1, Ts, count)
+            fresh = ~plane_born[ks:ke + 1]
+            n_active += int(plane_cells[ks:ke + 1][fresh].sum())
+            plane_born[ks:ke + 1] = True
+            st.set_mask_device(ks, ke + 1)
+            return
+        born = np.zeros_like(mask_full, dtype=bool)
+        born[:, :, ks:ke + 1] = mask_full[:, :, ks:ke + 1]
+        newborn = (born & (~mask_act))[i0:i1]
+        if newborn.any():
+            if on_device:
+                T[torch.from_numpy(newborn).to(T.device)] = Ts      # in place (the last sub-step sent no halo ahead)
+            else:
+                Tl = np.array(st.local_numpy(T))
+                Tl[newborn] = Ts
+                T = Tl
+        mask_act[...] = mask_act | born
+        n_active = int(mask_act.sum())
+        st.set_mask(mask_act[i0:i1])
+
+    for what, arg in layer_birth_schedule(times_birth, times_out):
+        if what == 'advance':
+            if n_active > 0:
+                advance(arg)
+        elif what == 'birth':
+            birth(*layers[arg])
+        elif on_frame is not None:
             act = st._logical(dist_slab._interior(st.d_mask_ext)).cpu().contiguous().numpy().astype(bool) if dev_loop \
                 else mask_act[i0:i1].copy()
-            on_frame(t_now, np.array(st.local_numpy(T)), act)
+            on_frame(arg, np.array(st.local_numpy(T)), act)
     return np.array(st.local_numpy(T)), nsteps
 
 

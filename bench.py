@@ -65,6 +65,8 @@ def parse(argv=None):
                     help='N > 1: nccl = RCCL, one rank per GPU (default, the product path); gloo-staged = a TEST transport that puts '
                          'every rank on cuda:0 and stages the payloads through pinned host memory (dist_slab.HostStagedDistComm): '
                          'runs the whole N > 1 code path with real processes on a one-GPU box; the line is marked')
+    ap.add_argument('--no-also', action='store_true',
+                    help='N = 1: skip the `also` object (the other BASELINE.json configs, 20 steps each, after the timed region)')
     ap.add_argument('--pg-timeout', type=float, default=120.0,
                     help='seconds a collective of the process group may wait before the rank aborts with a stack trace')
     return ap.parse_args(argv)
@@ -303,6 +305,96 @@ def parity_vs_one_domain(a, adi, dist_slab, dist, world, rank, mat, prm, dx, Tin
     except Exception as e:          # noqa: BLE001
         rec.update(rel_linf=None, ok=False, error='one-domain leg on rank 0: %s: %s' % (type(e).__name__, e))
     return rec
+
+
+def timed_steps(step_fn, nstages, steps=20, warmup=5, every=1):
+    """`steps` calls of step_fn(events or None) after `warmup` untimed ones: (ms per step between two events around the whole
+    loop, per-stage mean ms from events recorded on every `every`-th step -- small kernels notice their own event records)"""
+    for _ in range(warmup):
+        step_fn(None)
+    evs = {s_: [torch.cuda.Event(enable_timing=True) for _ in range(nstages + 1)] for s_ in range(steps) if s_ % every == 0}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for s_ in range(steps):
+        step_fn(evs.get(s_))
+    e1.record(); e1.synchronize()
+    st = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(nstages)] for e in evs.values()])
+    return e0.elapsed_time(e1) / steps, st.mean(axis=0)
+
+
+def _kernel_table(names, bpc, ms, cells):
+    out = {}
+    for nm, b, m in zip(names, bpc, ms):
+        gbs = b * cells / (m * 1e-3) / 1e9
+        out[nm] = dict(ms=round(float(m), 4), bytes_per_cell=round(float(b), 3), achieved_gbs=round(gbs, 1),
+                       frac=round(gbs / HBM_PEAK_GBS, 4))
+    return out
+
+
+def also_configs(a, adi, mat, prm, dx, Tinf, dev):
+    """The other BASELINE.json configurations and the per-voxel-h workload in the one line the driver records: 20 steps each
+    (5 warm-up), AFTER the timed region and outside it, fields resident in HBM, same event method.
+      config2_256                 configs[1]: 256^3 Cartesian Robin, all-solid
+      config4_cyl                 configs[3]: cylindrical 128 x 256 x 512 BE (the loop of `bench.py --config cyl`)
+      ellipsoid_<n>               the headline box holding a curved solid, per-face scalar h (`--mask ellipsoid`)
+      robin_field_ellipsoid_<n>   the same solid with PER-VOXEL Robin coefficients on five faces + a Neumann face: the packs
+                                  of the STL-corrected drivers (quick_compare_robin_end_robin_corrected.py:174-207,
+                                  voxel_bc_correction.py:110-167), whose sweeps load their coefficients behind the flags
+    Every entry: ms_per_step, steps_per_s, kernels {stage: ms, bytes_per_cell, achieved_gbs, frac}."""
+    out = {}
+
+    def cart(n_, mask, packs_kw, tag):
+        grid = adi.Grid3D(n_, n_, n_, dx, mask)
+        packs = adi.precompute_coeff_packs_unified(grid, mat, **packs_kw)
+        stp = adi.StagedStepper(grid, mat, prm, packs, Tinf)
+        gen = torch.Generator(device=dev); gen.manual_seed(5)
+        state = [adi.DeviceField(torch.rand((n_, n_, n_), dtype=torch.float64, device=dev, generator=gen) * 980.0 + 20.0)]
+
+        def step(ev):
+            state[0] = stp.step(state[0], events=ev)
+        ms, st = timed_steps(step, len(stp.stage_names), every=(4 if n_ <= 256 else 1))
+        assert bool(torch.isfinite(state[0].t).all().item())
+        out[tag] = dict(ms_per_step=round(ms, 4), steps_per_s=round(1e3 / ms, 2), cells=n_ ** 3,
+                        in_mask_fraction=round(float(np.mean(mask)), 4),
+                        bytes_per_cell_step=round(float(sum(stp.stage_bytes_per_cell)), 3),
+                        kernels=_kernel_table(stp.stage_names, stp.stage_bytes_per_cell, st, n_ ** 3))
+        del stp, packs, grid, state
+        torch.cuda.empty_cache()
+
+    cart(256, np.ones((256, 256, 256), bool), dict(robin_h=500.0), 'config2_256')
+    n = a.n
+    emask = make_mask('ellipsoid', (n, n, n))
+    cart(n, emask, dict(robin_h=500.0), 'ellipsoid_%d' % n)
+    # per-voxel h: a smooth field of the order of the scalar one (the corrected drivers scale h by a projected-area ratio per
+    # exposed voxel), built on the device; five faces carry it, 'z-' has none and takes a flux instead, as in the reference's driver
+    ax = [torch.linspace(0.0, 1.0, n, dtype=torch.float64, device=dev) for _ in range(3)]
+    hfield = 500.0 * (1.0 + 0.2 * torch.sin(7.0 * ax[0])[:, None, None] * torch.cos(5.0 * ax[1])[None, :, None]
+                      + 0.1 * torch.sin(9.0 * ax[2])[None, None, :])
+    cart(n, emask, dict(robin_h={f: hfield for f in ('x-', 'x+', 'y-', 'y+', 'z+')}, neumann={'z-': 2.0e5}),
+         'robin_field_ellipsoid_%d' % n)
+    del hfield
+    e, r = out['ellipsoid_%d' % n], out['robin_field_ellipsoid_%d' % n]
+    r['vs_scalar_h_ellipsoid'] = round(r['ms_per_step'] / e['ms_per_step'], 4)
+    r['target_vs_scalar_h'] = 1.10
+
+    import adi_thermal_fields_amd.adi3d_hip_cyl as cyl
+    nr, nphi, nz = 128, 256, 512
+    g = cyl.GridCyl(nr, nphi, nz, 2.5e-4, 2 * np.pi / nphi, 2.5e-4, 0.032)
+    cst = cyl.StagedCylStepper(g, cyl.Material(7800.0, 490.0, 54.0), cyl.Params(0.05, 1.0, "be"), cyl.RobinR(400.0, 20.0),
+                               cyl.ZBC('neumann0', 'robin', h_top=500.0, T_inf_top=20.0))
+    T0 = np.full((nr, nphi, nz), 20.0); T0[:, :, -16:] = 1000.0
+    X = g.layout.empty(); X.copy_(cyl.to_device(T0).t)
+    ms, st = timed_steps(lambda ev: cst._step_inplace(X, events=ev), 3, every=4)
+    N = nr * nphi * nz
+    kt = _kernel_table(cst.stage_names, cst.stage_bytes_per_cell, st, N)
+    dom = max(kt, key=lambda k: kt[k]['ms'])
+    out['config4_cyl'] = dict(ms_per_step=round(ms, 4), steps_per_s=round(1e3 / ms, 2), cells=N, kernels=kt,
+                              roofline=dict(bound='hbm', kernel=dom, achieved=kt[dom]['achieved_gbs'], peak=HBM_PEAK_GBS,
+                                            unit='GB/s', frac=kt[dom]['frac'], traffic=measured_traffic(dom, 'cyl')))
+    del cst, X
+    torch.cuda.empty_cache()
+    return out
 
 
 def main_cyl(a):
@@ -657,6 +749,8 @@ def main(argv=None):
                                           achieved=x['achieved_gbs'], peak=HBM_PEAK_GBS, unit='GB/s', frac=x['frac'],
                                           target_frac=0.60,
                                           lean_sparse_variant_in_step=kernels.get('sweep_axis2_contig'))
+    if not multi and not a.no_also:
+        line['also'] = also_configs(a, adi, mat, prm, dx, Tinf, dev)
     if not multi and not a.no_cpu:
         # parity of the very kernels that were timed: PARITY_STEPS steps of the timed stepper from T0 (or, with --cpu-n,
         # of the same workload at that edge) against the single-thread oracle leg started from the same host array

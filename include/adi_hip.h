@@ -34,7 +34,7 @@ extern "C" {
 #define ADI_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
 #define ADI_ERR_STATE       4   /* context used out of order (e.g. step before build_coeffs) */
 
-#define ADI_ABI_VERSION 17
+#define ADI_ABI_VERSION 18
 
 /* per-face BC data mode for adi_build_coeffs */
 #define ADI_FACE_NONE   0   /* face carries no data (robin_h is None / face absent from `neumann`) */
@@ -307,31 +307,42 @@ int adi_interface_solve_uniform(const double *d_g_all, const double *d_mat_all, 
                                 long nlines, double *d_xlo, double *d_xhi, void *stream);
 int adi_deferred_exact_coef(const double *d_xlo, const double *d_xhi, const double *d_kap, long nlines, double *d_clo,
                             double *d_chi, void *stream);
-/* The deferred form for lines that are NOT uniform (ABI v17: curved solids, voids, Dirichlet cells -- an STL part on slabs).
- * The algebra above needs no uniform rows, only the two homogeneous solutions of every line; where they decay across the slab
- * they are non-zero on K << nx planes at each end:
+/* The deferred form for lines that are NOT uniform (curved solids, voids, Dirichlet cells -- an STL part on slabs; ABI v17,
+ * reworked in v18).  The algebra above needs no uniform rows, only the two homogeneous solutions of every line; where they decay
+ * across the slab they are non-zero on K < nx planes at each end.  v17 streamed K planes of per-cell weights at each end into
+ * the axis-1 sweep (at cfl 200: 399 of 512 planes, more than the field itself).  v18 sorts the lines once per plan, per side,
+ * by what their first (last) K rows look like:
+ *     uniform  all K rows solid interior rows, no Dirichlet cell: the line's homogeneous solution IS the scalar w[i] of the
+ *              uniform deferred form on those rows (up to the decay tolerance) -> adi_sweep_corrected adds it, as for boxes;
+ *     off      all K rows outside the mask: identity rows, weight 0;
+ *     flagged  everything else (the line crosses a void, the surface or a Dirichlet cell within reach of the interface): its
+ *              own K weights, kept compactly as d_wc [K][nflag], and applied IN MEMORY to the zero-boundary solution by
+ *              adi_deferred_lines_apply before the axis-1 sweep -- a sparse pass over the flagged lines only.
  *   per plan   two ordinary adi_sweep(axis 0) calls on the slab with a zero field, Tinf = 0, no fluxes, zero Dirichlet values
- *              and d_xlo = 1 (resp. d_xhi = 1): w_lo, w_hi of every line; the caller keeps planes [0, K) of w_lo and
- *              [nx-K, nx) of w_hi (reversed: plane q = nx-1-i), checks that the rest is below its tolerance, and exchanges the
- *              planes next to the interfaces (om_* below) with the neighbours;
- *   per step   step 1 as above; adi_interface_deferred_lines: the 2 x 2 systems with per-line weights -> d_ulo, d_uhi;
- *              adi_sweep_corrected with d_wlo / d_whi: plane i reads  in + wlo[i][j][k] * ulo[j][k] + whi[nx-1-i][j][k] * uhi[j][k]
- *              on the planes where d_w (1 on its first weight_nplanes entries, 0 beyond) says there are weights.
+ *              and d_xlo = 1 (resp. d_xhi = 1): w_lo, w_hi of every line; the caller checks that they are below its tolerance
+ *              beyond K planes, sorts the lines, compacts the weights of the flagged ones and exchanges the planes next to the
+ *              interfaces (om_* below) with the neighbours;
+ *   per step   step 1 as above; adi_interface_deferred_lines: the 2 x 2 systems with per-line weights -> d_ulo, d_uhi (every
+ *              line) and d_ulo_uni / d_uhi_uni = the same values on the uniform lines, 0 elsewhere (d_uni_lo / d_uni_hi: one
+ *              byte per line, non-zero = uniform; all four NULL: not wanted); adi_deferred_lines_apply for each side;
+ *              adi_sweep_corrected with the scalar weights and the *_uni planes.
  * om_lo_own / om_hi_own: plane 0 of w_lo / plane nx-1 of w_hi of this rank; om_hi_prev / om_lo_next: the same planes of the
  * neighbours (dense ny*nz; NULL together with the neighbour's plane where there is none). */
 int adi_interface_deferred_lines(const double *d_first, const double *d_last, const double *d_prev_last,
                                  const double *d_next_first, const double *d_om_lo_own, const double *d_om_hi_prev,
                                  const double *d_om_hi_own, const double *d_om_lo_next, long nlines, double *d_ulo,
-                                 double *d_uhi, void *stream);
-/* d_wlo / d_whi (both NULL: the scalar weights d_w[i] / d_w[nx-1-i] of uniform lines): per-cell weights, weight_nplanes planes
- * each, weight_plane_stride >= ny*nz elements apart, the planes of d_whi counted from the far end; given for exactly the sides
- * whose interface plane (d_ulo / d_uhi) is given. */
+                                 double *d_uhi, const uint8_t *d_uni_lo, const uint8_t *d_uni_hi, double *d_ulo_uni,
+                                 double *d_uhi_uni, void *stream);
+/* x[i][cell[q]] += wc[r][q] * u[cell[q]]  for q < nflag, r < K, with plane i = r (from_high_end == 0) or nx-1-r: the rank-one
+ * update of the flagged lines of one side.  d_x: the slab field (nx planes, plane_stride elements apart); d_cells: nflag
+ * offsets of the flagged lines inside a plane (j*nz + k, ascending); d_wc: [K][nflag]; d_u: a dense (ny*nz) interface plane. */
+int adi_deferred_lines_apply(double *d_x, int nx, long plane_stride, long plane_cells, const int *d_cells, long nflag,
+                             const double *d_wc, int K, const double *d_u, int from_high_end, void *stream);
 int adi_sweep_corrected(int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
                         const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux,
                         int nx, int ny, int nz, long plane_stride, int sparse,
                         double theta, double gam, double dt, double Tinf,
                         double *d_out, const double *d_ulo, const double *d_uhi, const double *d_w,
-                        const double *d_wlo, const double *d_whi, long weight_plane_stride, int weight_nplanes,
                         const double *h_face_consts, void *d_work, size_t work_bytes, void *stream);
 
 /*

@@ -44,6 +44,7 @@ for seed in range(S0, S0 + N):
                 allow_deferred=bool(rng.random() < 0.85), allow_deferred_exact=bool(rng.random() < 0.8),
                 allow_deferred_lines=bool(rng.random() < 0.6))
     modes = set()
+    opts['cost_rule'] = bool(rng.random() < 0.5)
     got = D._run_slabs(c, world, sizes, 3, opts, modes)
     want = run_cart_case(hip, c)['T_final']
     err = rel_linf(got, want)

@@ -219,25 +219,27 @@ class CpuEngine:
         assert np.abs(B @ sol - t.T).max() <= 1e-9 * max(1.0, np.abs(t).max())           # the two-vector form is exact
         clo.numpy()[:] = sol[0]; chi.numpy()[:] = sol[1]
 
-    def sweep_corrected(self, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, ulo, uhi, w_corr, wlo=None, whi=None):
+    def sweep_corrected(self, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, ulo, uhi, w_corr):
         w = w_corr.numpy()
         x = t_in.numpy().copy()
-        n = Li.nx
         if ulo is not None:
-            u = ulo.numpy().reshape(1, Li.ny, Li.nz)
-            if wlo is not None:                # per-cell weights on the planes where w says so
-                K = wlo.shape[0]
-                x[:K] += w[:K, None, None] * wlo.numpy() * u
-            else:
-                x += w[:, None, None] * u
+            x += w[:, None, None] * ulo.numpy().reshape(1, Li.ny, Li.nz)
         if uhi is not None:
-            u = uhi.numpy().reshape(1, Li.ny, Li.nz)
-            if whi is not None:                # plane q of whi belongs to slab plane n-1-q
-                K = whi.shape[0]
-                x[n - K:] += (w[:K, None, None] * whi.numpy())[::-1] * u
-            else:
-                x += w[::-1][:, None, None] * u
+            x += w[::-1][:, None, None] * uhi.numpy().reshape(1, Li.ny, Li.nz)
         self.sweep(1, variant, Li, torch.from_numpy(x), flags, pack, theta, gam, dt, Tinf, t_out)
+
+    def deferred_lines_apply(self, Li, x, cells, wc, u, from_high_end):
+        """the flagged lines of one side get their own weights, in place (include/adi_hip.h, adi_deferred_lines_apply)"""
+        if cells.numel() == 0:
+            return
+        xv = x.numpy().reshape(Li.nx, -1)                 # (a view: x is a dense (nx, ny, nz) tensor on CPU ranks)
+        assert np.shares_memory(xv, x.numpy())
+        c = cells.numpy().astype(np.int64)
+        K = wc.shape[0]
+        uu = u.numpy().reshape(-1)[c]
+        rows = np.arange(K)
+        planes = (Li.nx - 1 - rows) if from_high_end else rows
+        xv[planes[:, None], c[None, :]] += wc.numpy() * uu[None, :]
 
     # the deferred form with per-line homogeneous solutions (include/adi_hip.h, ABI v17), restated with dense solves
     def homogeneous_solution(self, variant, Li, flags, pack, theta, gam, dt, lower):
@@ -248,7 +250,8 @@ class CpuEngine:
                    xlo=one if lower else None, xhi=None if lower else one)
         return out
 
-    def interface_deferred_lines(self, first, last, prev_last, next_first, om, nlines, ulo, uhi):
+    def interface_deferred_lines(self, first, last, prev_last, next_first, om, nlines, ulo, uhi, uni_lo=None, uni_hi=None,
+                                 ulo_uni=None, uhi_uni=None):
         f, l = first.numpy().reshape(-1), last.numpy().reshape(-1)
         lo = np.zeros(nlines); hi = np.zeros(nlines)
         if prev_last is not None:
@@ -260,6 +263,10 @@ class CpuEngine:
             wh, wl = om['hi_own'].numpy().reshape(-1), om['lo_next'].numpy().reshape(-1)
             hi = (next_first.numpy().reshape(-1) + wl * l) / (1.0 - wl * wh)
         ulo.copy_(torch.from_numpy(lo)); uhi.copy_(torch.from_numpy(hi))
+        if ulo_uni is not None:
+            ulo_uni.copy_(torch.from_numpy(lo * (uni_lo.numpy().reshape(-1) != 0) if uni_lo is not None else 0.0 * lo))
+        if uhi_uni is not None:
+            uhi_uni.copy_(torch.from_numpy(hi * (uni_hi.numpy().reshape(-1) != 0) if uni_hi is not None else 0.0 * hi))
 
     def sweep(self, axis, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf, t_out, xlo=None, xhi=None):
         a, b, c, d = _line_systems(axis, t_in, flags, pack, theta, gam, dt, Tinf)

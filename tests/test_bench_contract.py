@@ -42,6 +42,17 @@ def test_single_gpu_line_with_cpu_baseline_and_parity():
     assert cb['kind'] == 'port' and cb['cores'] == 1 and d['cpu_baseline_all_cores']['cores'] >= 1
     assert d['parity_rel_linf'] <= 1e-10 and d['parity']['steps'] == 3
     assert 'north_star_x_sweep' in d and d['north_star_x_sweep']['target_frac'] == 0.60
+    # the other BASELINE.json configurations ride in the same line (after the timed region)
+    al = d['also']
+    assert set(al) == {'config2_256', 'config4_cyl', 'ellipsoid_64', 'robin_field_ellipsoid_64'}
+    for k, v in al.items():
+        assert v['ms_per_step'] > 0 and v['steps_per_s'] > 0 and len(v['kernels']) >= 3, k
+        for kk in v['kernels'].values():
+            assert kk['ms'] > 0 and kk['bytes_per_cell'] >= 16 and 0 < kk['frac'] < 1, (k, kk)
+    assert al['config4_cyl']['roofline']['bound'] == 'hbm' and set(al['config4_cyl']['kernels']) == {'sweep_r', 'sweep_phi', 'sweep_z_contig'}
+    rf = al['robin_field_ellipsoid_64']
+    assert rf['bytes_per_cell_step'] > al['ellipsoid_64']['bytes_per_cell_step']      # its sweeps load coefficient arrays
+    assert rf['target_vs_scalar_h'] == 1.10 and rf['vs_scalar_h_ellipsoid'] > 0
 
 
 @pytest.mark.parametrize('scaling,form', [('weak', 'deferred_exact'), ('strong', 'deferred_exact')])   # (256 rows at cfl 200: no decay)

@@ -20,7 +20,7 @@ def test_header_symbols_exported_and_bound():
         assert n in _lib.SIGNATURES, 'ctypes binding missing for %s' % n
     for n in _lib.SIGNATURES:
         assert n in names, '%s bound but not declared in include/adi_hip.h' % n
-    assert _lib.lib.adi_abi_version() == 17
+    assert _lib.lib.adi_abi_version() == 18
 
 
 def test_argument_errors_without_gpu():

@@ -54,7 +54,27 @@ def _solid_case(nx, cfl):
     return c
 
 
+def _cavity_case(nx, cfl):
+    """a solid box with cavities close to the slab interfaces and a few Dirichlet cells: most sharded-axis lines are uniform
+    within reach of an interface (scalar weights), the ones through a cavity or a Dirichlet cell are flagged (own weights),
+    the ones inside a channel that runs along the sharded axis are off-mask near the interface (weight 0)"""
+    c = _solid_case(nx, cfl)
+    shape = c['shape']
+    g = np.meshgrid(*[(np.arange(n) + 0.5) / n - 0.5 for n in shape], indexing='ij')
+    mask = np.ones(shape, bool)
+    for ci in (-0.27, 0.02, 0.24):
+        mask &= ~(((g[0] - ci) / 0.07) ** 2 + ((g[1] - 0.1) / 0.25) ** 2 + ((g[2] + 0.1) / 0.2) ** 2 <= 1.0)
+    mask[:, :3, :4] = False                                 # a channel along the sharded axis: lines wholly outside the mask
+    rng = np.random.default_rng(5)
+    dm = (rng.random(shape) < 0.002) & mask
+    c.update(mask=mask, dir_mask=dm, dir_value=rng.uniform(50.0, 300.0, shape))
+    return c
+
+
 def _case(name):
+    if name.startswith('cavity:'):
+        _, nx, cfl = name.split(':')
+        return _cavity_case(int(nx), float(cfl))
     if name.startswith('solid:'):
         _, nx, cfl = name.split(':')
         return _solid_case(int(nx), float(cfl))
@@ -101,6 +121,9 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q, opts=None):
         st._allow_deferred_exact = bool(opts.get('allow_deferred_exact', True))
         # (off unless a test asks for it: the cases below were written for the two-pass forms it would otherwise replace)
         st._allow_deferred_lines = bool(opts.get('allow_deferred_lines', False))
+        # (the test solids are riddled with voids -- nearly every line is flagged, which exercises the sparse pass on all of them;
+        # the product's cost rule would leave such a solid to the window form: 'cost_rule' keeps it on)
+        st._deferred_lines_cost_ratio = 1.0 if opts.get('cost_rule') else float('inf')
         T = torch.from_numpy(np.ascontiguousarray(c['T0'][i0:i1]))
         for s in range(nsteps):
             T = st.step(T, prefetch_halo=bool(opts.get('prefetch', False)) and s + 1 < nsteps)
@@ -342,6 +365,23 @@ def test_host_staged_transport_and_slab_gather(world, name, sizes, opts):
     c = _case(name)
     got, _ = _run_world(world, name, sizes, c['nsteps'], dict(opts, staged=True))
     assert rel_linf(got, run_cart_case(orc, c)['T_final']) <= 1e-12
+
+
+@pytest.mark.parametrize('world,name,sizes', [(2, 'cavity:128:0.5', [64, 64]), (3, 'cavity:190:0.5', [64, 62, 64]),
+                                              (4, 'cavity:256:0.5', [64] * 4)])
+def test_deferred_lines_with_the_cost_rule_on_a_part_with_cavities(world, name, sizes):
+    """the three kinds of line at once -- uniform within reach (scalar weights inside the axis-1 sweep), flagged (own weights
+    from the sparse pass), off-mask (none) -- with the product's cost rule deciding: a solid box with three cavities, a channel
+    along the sharded axis and scattered Dirichlet cells"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import adi_oracle as orc
+    from helpers import run_cart_case, rel_linf
+    c = _case(name)
+    got, modes = _run_world(world, name, sizes, c['nsteps'], dict(prefetch=True, allow_deferred_lines=True, cost_rule=True))
+    assert modes == {'deferred_lines'}, modes
+    want = run_cart_case(orc, c)['T_final']
+    assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
+    assert np.array_equal(got[~c['mask']], c['T0'][~c['mask']])
 
 
 def test_deferred_form_with_per_line_solutions_is_decided_collectively_on_one_plane_slabs():

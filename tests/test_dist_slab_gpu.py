@@ -45,6 +45,9 @@ def _run_slabs(c, world, sizes, nsteps, opts=None, modes=None):
             st._allow_deferred_exact = bool(o.get('allow_deferred_exact', True))
             # (off unless a test asks for it: most cases here were written for the two-pass forms it would otherwise replace)
             st._allow_deferred_lines = bool(o.get('allow_deferred_lines', False))
+            # (solids riddled with voids: every line is flagged -- the sparse pass at its fullest; the product's cost rule would
+            # leave them to the window form unless a case asks for the rule with 'cost_rule')
+            st._deferred_lines_cost_ratio = 1.0 if o.get('cost_rule') else float('inf')
             if 'dots_max' in o:
                 st.DOTS_MAX_NONUNIFORM = o['dots_max']
             T = hip.to_device(np.ascontiguousarray(c['T0'][i0:i1]))
@@ -342,11 +345,13 @@ def test_slabs_on_ragged_planes(shape, kind, world, opts):
     ((1024, 16, 32), 'ellipsoid', [512, 512], 40.0, dict(prefetch=True)),                      # the bench's slab thickness, K = 183
     ((192, 70, 90), 'ellipsoid', [64] * 3, 0.3, dict(prefetch=True)),                          # padded planes
     ((192, 24, 40), 'holes', [64] * 3, 0.3, dict(prefetch=True, no_pad=True)),                 # GENERAL axis-1 kernels
+    ((256, 64, 96), 'cavity', [128, 128], 3.0, dict(prefetch=True, cost_rule=True)),          # a part with a cavity: the cost rule takes it
 ])
 def test_slabs_deferred_form_with_per_line_solutions(shape, kind, sizes, cfl, opts):
-    """lines that are not uniform ('deferred_lines', ABI v17): per-line homogeneous solutions from two axis-0 sweeps per plan,
-    the per-line 2 x 2 interface systems, correction planes on the K planes at each end added by the axis-1 sweep's loads
-    (FAST and GENERAL strided kernels) -- against the single-domain HIP step and the oracle"""
+    """lines that are not uniform ('deferred_lines', ABI v17 / v18): per-line homogeneous solutions from two axis-0 sweeps per
+    plan, the per-line 2 x 2 interface systems; lines that are uniform within reach of an interface take the scalar weights inside
+    the axis-1 sweep (FAST and GENERAL strided kernels), the flagged ones -- crossing a void, the surface or a Dirichlet cell --
+    their own weights from the sparse in-memory pass (adi_deferred_lines_apply) -- against the single-domain HIP step and the oracle"""
     import adi_thermal_fields_amd.adi3d_hip_coeff as hip
     from oracle import adi_oracle as orc
     rng = np.random.default_rng(sum(shape))
@@ -358,6 +363,11 @@ def test_slabs_deferred_form_with_per_line_solutions(shape, kind, sizes, cfl, op
     elif kind == 'ellipsoid':
         g = np.meshgrid(*[(np.arange(s) + 0.5) / s - 0.5 for s in shape], indexing='ij')
         mask = (g[0] / 0.49) ** 2 + (g[1] / 0.46) ** 2 + (g[2] / 0.47) ** 2 <= 1.0
+    elif kind == 'cavity':
+        # a prism along the sharded axis with an off-centre cavity near the interface: most lines are uniform within reach
+        g = np.meshgrid(*[(np.arange(s) + 0.5) / s - 0.5 for s in shape], indexing='ij')
+        mask = ((g[1] / 0.47) ** 2 + (g[2] / 0.45) ** 2 <= 1.0) & \
+            ~(((g[0] + 0.05) / 0.1) ** 2 + ((g[1] - 0.1) / 0.15) ** 2 + (g[2] / 0.2) ** 2 <= 1.0)
     else:
         mask = rng.random(shape) > 0.02
         dm = (rng.random(shape) < 0.01) & mask

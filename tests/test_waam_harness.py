@@ -53,6 +53,38 @@ def test_layers_and_times_match_the_reference_restatement(seed):
         assert t_new == t_ref
 
 
+@pytest.mark.parametrize('seed', range(6))
+def test_schedule_is_the_reference_event_loop(seed):
+    """waam.layer_birth_schedule against the loop of waam_from_stl_v7_mm.py:515-550 written out action by action: same
+    actions, same order, same intervals (bit for bit), with births that coincide with output times, output times before the
+    first birth and after the last one, and simultaneous births"""
+    from adi_thermal_fields_amd import waam
+    rng = np.random.default_rng(seed)
+    tb = list(np.cumsum(rng.uniform(0.0, 2.0, 12)))
+    if seed % 2:
+        tb[5] = tb[4]                                            # two layers born at the same time
+    to = sorted(set([0.5 * tb[0], tb[3], tb[-1], tb[-1] + 3.0] + list(rng.uniform(0.0, tb[-1], 4))))
+    want, nb, t_now = [], 0, 0.0
+    for te in sorted(set(to + tb)):
+        while nb < len(tb) and tb[nb] <= te + 1e-15:
+            seg = max(0.0, tb[nb] - t_now)
+            if seg > 1e-15:
+                want.append(('advance', seg))
+            t_now = tb[nb]
+            want.append(('birth', nb))
+            nb += 1
+        seg = max(0.0, te - t_now)
+        if seg > 1e-15:
+            want.append(('advance', seg))
+        t_now = te
+        if any(abs(te - x) <= 1e-12 for x in to):
+            want.append(('frame', te))
+    got = list(waam.layer_birth_schedule(tb, to))
+    assert got == want
+    assert [a for w, a in got if w == 'birth'] == list(range(12))
+    assert abs(sum(a for w, a in got if w == 'advance') - max(to)) <= 1e-9
+
+
 def test_layer_birth_loop_on_oracle_runs():
     """the loop itself is backend-agnostic: run it on the CPU oracle (tiny grid)"""
     from oracle import adi_oracle as orc
