@@ -9,10 +9,17 @@ extern "C" {
 
 long adi_recommended_plane_stride(int ny, int nz)
 {
-    // planes whose byte size is a multiple of 16 KiB alias on the HBM channel interleave when walked with
-    // that stride (axis-0 sweeps): pad by 256 elements (2 KiB; a sweep over 64..4608 showed 256 a few percent ahead on the axis-0 sweep).
-    const long dense = (long)ny * nz;
-    return (dense * 8 % 16384 == 0) ? dense + 256 : dense;
+    // Planes whose byte size is a multiple of 16 KiB alias on the HBM channel interleave when walked with that stride (the
+    // axis-0 sweeps: every row of a tile falls on the same channels -- 512^3 dense 2.7 TB/s against 4.0 padded), so the pitch
+    // grows by a few hundred bytes.  HOW many depends on the plane: round 1 swept the pad on 2 MiB planes only and took 256
+    // elements; round 4 (scripts/pitch_probe.py, fused explicit + axis-0 kernel, Gcell/s) found that very pad to be the WORST
+    // choice for 512 KiB planes -- (512, 256, 256): 142 - 149 with 256, 166 - 175 with 16 ... 192 -- and 128 the worst for
+    // 256 KiB planes (143 - 164 against 189 with 64), 64 the worst for 128 KiB planes (145 against 170), 1024 / 2048 for 1 / 2 MiB
+    // planes (92 - 98 and 87 against 180 - 200).  The table below avoids every measured cliff:
+    //     plane < 192 KiB: 256 elements    192 KiB ... < 768 KiB: 64    from 768 KiB: 128  (2 MiB: 203 against 199 with 256)
+    const long dense = (long)ny * nz, bytes = dense * 8;
+    if (bytes % 16384 != 0) return dense;
+    return dense + (bytes < (192L << 10) ? 256 : (bytes < (768L << 10) ? 64 : 128));
 }
 
 // Physical extents for a (nx, ny, nz) grid: per axis the length -- the logical one or a few multiples of 16 above it --

@@ -535,9 +535,14 @@ __global__ __launch_bounds__(256) void k_deferred_lines_apply(double *__restrict
     const long cell = cells[q];
     const double uu = u[cell];
     for (int r = blockIdx.y; r < K; r += gridDim.y) {
-        const long i = from_hi ? (long)(nx - 1 - r) : (long)r;
-        double *p = x + i * sx + cell;
-        *p = __builtin_fma(wc[(long)r * nflag + q], uu, *p);
+        // a flagged line's weights are exact zeros beyond its first row outside the mask (identity rows cut the coupling): a
+        // line through a cavity 150 planes from the interface carries 150 weights, not K; x + 0 * u = x is skipped unread
+        const double w = wc[(long)r * nflag + q];
+        if (w != 0.0) {
+            const long i = from_hi ? (long)(nx - 1 - r) : (long)r;
+            double *p = x + i * sx + cell;
+            *p = __builtin_fma(w, uu, *p);
+        }
     }
 }
 

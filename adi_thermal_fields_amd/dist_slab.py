@@ -653,6 +653,8 @@ class SlabStepper:
         self._allow_deferred_lines = True          # False: lines that are not uniform keep the two-pass forms
         self._deferred_lines_cost_ratio = 1.0      # ... and so do slabs whose flagged lines cost more than this x pass A (tests: inf)
         self._plan_steps = None                    # steps taken under the current axis-0 plan (None: no plan yet)
+        self._allow_quick_replan = True            # False: every plan is made by the full (measuring) planner
+        self._dots_sticky, self._nx_all, self._fused_by_K, self._chunk_cache = None, None, {}, {}
         self._send_g_only = True                   # False: every step exchanges the matrix parts of the interface too
         self._comm_stream, self._use_streams = None, False
         self._halo_ready, self._halo_event = None, None
@@ -896,7 +898,7 @@ class SlabStepper:
         prm = self.params
         key = (float(prm.dt), float(prm.theta), self._mask_version, self._force_exact, self._no_overlap,
                self._allow_fused, self._allow_window, self._keep_r0, self._allow_dots, self._allow_deferred,
-               self._allow_deferred_exact, self._allow_deferred_lines, self._deferred_lines_cost_ratio)
+               self._allow_deferred_exact, self._allow_deferred_lines, self._deferred_lines_cost_ratio, self._allow_quick_replan)
         if self._a0_key == key:
             self._plan_steps += 1
             return self._a0
@@ -908,6 +910,12 @@ class SlabStepper:
         self._streams()
         nl, fl, pk = self.nlines, self.flags_int, self.packs_int[0]
         first, last = self.rank == 0, self.rank == self.world - 1
+        if short_lived and self._allow_quick_replan:
+            plan = self._quick_plan(gam)
+            if plan is not None:
+                self._a0_key, self._a0 = key, plan
+                self.axis0_mode = plan['mode']
+                return plan
         # Every rank evaluates BOTH candidate forms on its own slab and the form is agreed collectively: the eligibility
         # of 'window' (4 K <= planes of this rank) and the decay tests depend on the rank's slab -- split_planes hands out
         # slabs that differ by two planes -- and ranks running different forms would exchange messages of different sizes
@@ -1065,8 +1073,97 @@ class SlabStepper:
                 b['next_lo'] = E.vec(2 * n)        # (gF, aF) of the slab above
             bufs.append(b)
         plan['chunks'] = bufs
+        if plan['mode'] != 'window':
+            self._dots_sticky = bool(plan['dots'])          # (a re-plan of a short-lived plan keeps this decision, _quick_plan)
         self._a0_key, self._a0 = key, plan
         self.axis0_mode = plan['mode']
+        return plan
+
+    # ---- re-planning inside an event loop ---------------------------------------------------------------------------------
+    # A layer-birth loop changes the mask and the time step at every birth, i.e. the plan lives for a step or two, and the
+    # full planner above costs eight host synchronisations per plan (the measured decay of the condensed entries, the
+    # collective flags, the share of non-uniform lines): 0.5 ms per birth, 44 % of the per-rank loop of BASELINE.json
+    # configs[4] on 64-plane slabs (scripts/waam_slab_profile.py).  While plans are short-lived they are made WITHOUT reading
+    # anything back:
+    #   * the interface form from the rigorous bound instead of the measurement: the coupling through k rows is at most rho^k,
+    #     rho the per-row factor of solid interior rows (-tg, 1+2tg, -tg) -- every other row is more dominant, a row that lacks a
+    #     neighbour or is a Dirichlet cell cuts the coupling altogether -- so rho^K <= DECAY_TOL with 4 K <= the thinnest slab
+    #     proves 'window', rho^n <= DECAY_TOL proves 'slab', and 'exact' is always valid.  (The measurement can accept 'slab' where
+    #     the bound cannot -- thin-walled parts whose lines never run through a whole slab; the next long-lived plan measures again.)
+    #   * whether the fused kernels take the slab: a function of the extents, agreed collectively once per K;
+    #   * dot-product or tiled pass A: what the last full plan found (a performance choice, both are exact);
+    #   * the interface buffers of the previous plan of the same form are reused.
+    # Everything above is the same on every rank, so the ranks keep agreeing on the form without talking.
+    def _slab_planes_of_all_ranks(self):
+        if self._nx_all is None:
+            E = self.engine
+            mine, allv = E.vec(1), E.vec(self.world)
+            mine.fill_(float(self.nxl))
+            self.comm.all_gather(allv, mine)
+            self._nx_all = [int(round(float(x))) for x in allv.tolist()]
+        return self._nx_all
+
+    def _fused_collective(self, K):
+        if K not in self._fused_by_K:
+            E = self.engine
+            flag, allf = E.vec(1), E.vec(self.world)
+            flag.fill_(1.0 if self._fused_supported(K) else 0.0)
+            self.comm.all_gather(allf, flag)
+            self._fused_by_K[K] = bool(float(allf.min()) >= 1.0)
+        return self._fused_by_K[K]
+
+    def _quick_plan(self, gam):
+        """plan for the current (dt, theta, mask) without a host synchronisation, or None (no full plan has been made yet, or
+        the slab is an all-solid box: the deferred forms need the full planner)"""
+        E, prm = self.engine, self.params
+        if self._dots_sticky is None or getattr(self, '_solid_everywhere', False) or getattr(E, 'box_hint', 0) == 2:
+            return None
+        nmin = min(self._slab_planes_of_all_ranks())
+        Kg = self._window_guess(gam)
+        if self._force_exact or prm.theta * gam <= 0.0:
+            mode, K = 'exact', self.nxl
+        elif self._allow_window and 4 * Kg <= nmin:
+            mode, K = 'window', Kg
+        elif Kg <= nmin:
+            mode, K = 'slab', self.nxl
+        else:
+            mode, K = 'exact', self.nxl
+        plan = dict(mode=mode, K=K, quick=True)
+        if mode != 'exact':
+            plan.update(Lw=E.layout(K, self.ny, self.nz, self.Lint.sx), worst=None)
+        plan['fused'] = self._fused_collective(K)
+        plan['keep_r0'] = bool(plan['fused'] and mode != 'window' and self._keep_r0)
+        plan['dots'] = bool(self._dots_sticky and self._allow_dots and mode != 'window' and hasattr(E, 'dots_setup')
+                            and E.dots_supported(self.nxl, self.ny, self.nz, self.Lint.sx))
+        if plan['dots']:
+            plan['dd'] = E.dots_setup(self.Lint, self.flags_int, self.packs_int[0][1], prm.theta, gam)
+            plan['fused'] = plan['keep_r0'] = False
+        if plan['dots'] or mode == 'window':
+            ranges = self._chunk_ranges(1)
+        elif mode == 'exact':
+            ranges = self._chunk_ranges(4 if self.nxl * self.ny * self.nz >= (1 << 25) else 1)
+        else:
+            ranges = self._chunk_ranges(2, self.SLAB_CHUNK_EDGES)
+        ck = (mode, K, tuple(ranges))
+        bufs = self._chunk_cache.get(ck)
+        if bufs is None:
+            bufs = []
+            for j0, j1 in ranges:
+                n = (j1 - j0) * self.nz
+                b = dict(j0=j0, j1=j1, nl=n, Lc=E.layout(K, j1 - j0, self.nz, self.Lint.sx),
+                         Lb=E.layout(self.nxl, j1 - j0, self.nz, self.Lint.sx), xlo=E.vec(n), xhi=E.vec(n))
+                if mode == 'exact':
+                    b.update(cond=E.vec(6 * n), cond_all=E.vec(6 * n * self.world))
+                else:
+                    b['cond_hi'] = E.vec(6 * n)
+                    b['cond_lo'] = E.vec(6 * n) if mode == 'window' else b['cond_hi']
+                    b['prev_hi'] = E.vec(3 * n)
+                    b['next_lo'] = E.vec(2 * n)
+                bufs.append(b)
+            self._chunk_cache[ck] = bufs
+        for b in bufs:
+            b.pop('matrix_sent', None)            # a new plan: the matrix parts of the interface travel again
+        plan['chunks'] = bufs
         return plan
 
     def _plan_deferred_lines(self, fl, pk, gam, fused_ok):

@@ -125,8 +125,16 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q, opts=None):
         # the product's cost rule would leave such a solid to the window form: 'cost_rule' keeps it on)
         st._deferred_lines_cost_ratio = 1.0 if opts.get('cost_rule') else float('inf')
         T = torch.from_numpy(np.ascontiguousarray(c['T0'][i0:i1]))
+        st._allow_quick_replan = bool(opts.get('quick_replan', True))
+        modes_seen = []
         for s in range(nsteps):
-            T = st.step(T, prefetch_halo=bool(opts.get('prefetch', False)) and s + 1 < nsteps)
+            if opts.get('dt_seq'):                 # an event loop: the time step changes from step to step (new plan each time)
+                st.params.dt = c['dt'] * opts['dt_seq'][s]
+            T = st.step(T, prefetch_halo=bool(opts.get('prefetch', False)) and s + 1 < nsteps and not opts.get('dt_seq'))
+            modes_seen.append((st.axis0_mode, bool((st._a0 or {}).get('quick'))))
+        if opts.get('dt_seq'):
+            q.put((rank, T.numpy().copy(), tuple(modes_seen)))
+            return
         if opts.get('staged'):             # ... and the gather bench.py / tests/dist_hip_worker.py use: the whole field on rank 0
             full = dist_slab.gather_slabs(T, sizes, host_staged=True)
             assert (full is None) == (rank != 0)
@@ -382,6 +390,36 @@ def test_deferred_lines_with_the_cost_rule_on_a_part_with_cavities(world, name, 
     want = run_cart_case(orc, c)['T_final']
     assert rel_linf(got, want) <= 1e-12, rel_linf(got, want)
     assert np.array_equal(got[~c['mask']], c['T0'][~c['mask']])
+
+
+@pytest.mark.parametrize('world,sizes', [(2, [32, 32]), (3, [22, 20, 22])])
+def test_short_lived_plans_are_made_without_measuring(world, sizes):
+    """an event loop changes the time step (and the mask) from step to step; after the first plan SlabStepper re-plans from the
+    rigorous decay bound, without host synchronisations (_quick_plan): a sequence of time steps that walks through the window,
+    slab and all-gather forms, every rank agreeing on each, against the oracle stepping one domain with the same sequence"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import adi_oracle as orc
+    from helpers import rel_linf
+    name = 'decay:%d' % sum(sizes)
+    c = _case(name)
+    seq = [1.0, 1.0, 0.02, 0.5, 30.0, 0.02, 3000.0, 2.0, 0.01]          # multiples of the case's dt (cfl 0.1)
+    got, modes = _run_world(world, name, sizes, len(seq), dict(dt_seq=seq))
+    assert len(modes) == 1                                               # every rank saw the same sequence of forms
+    hist = list(modes)[0]
+    assert not hist[0][1] and all(qk for _, qk in hist[2:]), hist        # the first plan is measured, the later ones are quick
+    assert {'exact', 'window' if min(sizes) >= 32 else 'slab'} <= {m for m, _ in hist}, hist      # (a window needs 4 K <= planes)
+    grid = orc.Grid3D(*c['shape'], c['dx'], c['mask'])
+    mat = orc.Material(**c['mat'])
+    packs = orc.precompute_coeff_packs_unified(grid, mat, dir_mask=c['dir_mask'], dir_value=c['dir_value'], neumann=c['neumann'],
+                                               robin_h=c['robin_h'])
+    T = np.array(c['T0'])
+    for f in seq:
+        T = orc.adi_step_numba_coeff(T, grid, mat, orc.Params(c['dt'] * f, c['theta']), packs, Tinf=c['Tinf'])
+    assert rel_linf(got, T) <= 1e-12, rel_linf(got, T)
+    # the same sequence with the measuring planner throughout: the same fields to rounding
+    got2, modes2 = _run_world(world, name, sizes, len(seq), dict(dt_seq=seq, quick_replan=False))
+    assert not any(qk for _, qk in list(modes2)[0])
+    assert rel_linf(got2, T) <= 1e-12
 
 
 def test_deferred_form_with_per_line_solutions_is_decided_collectively_on_one_plane_slabs():
