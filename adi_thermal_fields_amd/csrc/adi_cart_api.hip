@@ -16,10 +16,11 @@ long adi_recommended_plane_stride(int ny, int nz)
     // choice for 512 KiB planes -- (512, 256, 256): 142 - 149 with 256, 166 - 175 with 16 ... 192 -- and 128 the worst for
     // 256 KiB planes (143 - 164 against 189 with 64), 64 the worst for 128 KiB planes (145 against 170), 1024 / 2048 for 1 / 2 MiB
     // planes (92 - 98 and 87 against 180 - 200).  The table below avoids every measured cliff:
-    //     plane < 192 KiB: 256 elements    192 KiB ... < 768 KiB: 64    from 768 KiB: 128  (2 MiB: 203 against 199 with 256)
+    //     plane < 192 KiB: 256 elements    192 KiB ... < 768 KiB: 64    from 768 KiB: 256 (as before: on 1 and 2 MiB planes 128
+    //     and 256 measure the same within the box-to-box scatter, and the headline workload keeps the pitch it was tuned on)
     const long dense = (long)ny * nz, bytes = dense * 8;
     if (bytes % 16384 != 0) return dense;
-    return dense + (bytes < (192L << 10) ? 256 : (bytes < (768L << 10) ? 64 : 128));
+    return dense + ((bytes >= (192L << 10) && bytes < (768L << 10)) ? 64 : 256);
 }
 
 // Physical extents for a (nx, ny, nz) grid: per axis the length -- the logical one or a few multiples of 16 above it --
