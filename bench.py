@@ -21,6 +21,7 @@ Prints ONE JSON line on rank 0.  `value` = 512^3-cell-equivalent ADI steps per s
 ranks (= plain steps/s at N = 1, n = 512).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -307,6 +308,17 @@ def parity_vs_one_domain(a, adi, dist_slab, dist, world, rank, mat, prm, dx, Tin
     return rec
 
 
+def quiet_gc():
+    """Python's cyclic collector out of the timed region, as `timeit` does: a full collection over the heap of a process that
+    has imported torch takes 35 - 60 ms and fires whenever the allocation counters say so -- scripts/slab_outlier_probe.py
+    caught it in the middle of a step loop (one 38 - 58 ms step among 1.2 ms ones, no allocator or kernel activity behind it):
+    the "36 ms outliers" of round 3.  Collect now, park the survivors in the permanent generation, switch the collector off;
+    the caller switches it on again after the loop."""
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+
+
 def timed_steps(step_fn, nstages, steps=20, warmup=5, every=1):
     """`steps` calls of step_fn(events or None) after `warmup` untimed ones: (ms per step between two events around the whole
     loop, per-stage mean ms from events recorded on every `every`-th step -- small kernels notice their own event records)"""
@@ -314,11 +326,13 @@ def timed_steps(step_fn, nstages, steps=20, warmup=5, every=1):
         step_fn(None)
     evs = {s_: [torch.cuda.Event(enable_timing=True) for _ in range(nstages + 1)] for s_ in range(steps) if s_ % every == 0}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    quiet_gc()
     torch.cuda.synchronize()
     e0.record()
     for s_ in range(steps):
         step_fn(evs.get(s_))
     e1.record(); e1.synchronize()
+    gc.enable()
     st = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(nstages)] for e in evs.values()])
     return e0.elapsed_time(e1) / steps, st.mean(axis=0)
 
@@ -439,11 +453,13 @@ def main_cyl(a):
     # only (the others run the same launches without them), so that the events do not set the step time they measure
     sampled = [s_ for s_ in range(a.steps) if s_ % 4 == 0]
     ev = {s_: [torch.cuda.Event(enable_timing=True) for _ in range(4)] for s_ in sampled}
+    quiet_gc()
     sync()
     t0 = time.perf_counter()
     for s_ in range(a.steps):
         st._step_inplace(X, events=ev.get(s_))
     sync()
+    gc.enable()
     T = cyl.DeviceField(X)
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     if world > 1:
@@ -635,12 +651,14 @@ def main(argv=None):
         stage_names = stepper.stage_names                  # depends on the axis-0 plan chosen for this dt / mask
     nst = len(stage_names)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(a.steps)]
+    quiet_gc()                                      # (no cyclic collection inside the timed region, see quiet_gc)
     sync()
     t0 = time.perf_counter()
     for s in range(a.steps):
         T = stepper.step(T, events=ev[s], **kw)     # HIP events on the launch stream between the stage kernels
     sync()
     t1 = time.perf_counter()
+    gc.enable()
     elapsed = col.max(t1 - t0)
     assert bool(torch.isfinite(T.t).all().item())
 

@@ -25,11 +25,15 @@ for shape in shapes:
             for _ in range(40):                    # (plans, promises and first allocations settle in the first tens of steps)
                 T = st.step(T, prefetch_halo=True)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(30):
+            # per-step times between events: the MEDIAN is reported -- one cyclic garbage collection of the Python heap (35 - 60 ms,
+            # scripts/slab_outlier_probe.py) inside a 30-step loop once put 2.400 ms where the steps take 1.2
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(31)]
+            evs[0].record()
+            for k in range(30):
                 T = st.step(T, prefetch_halo=True)
-            e1.record(); torch.cuda.synchronize()
+                evs[k + 1].record()
+            torch.cuda.synchronize()
+            per = np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(30)])
             names = st.stage_names
             ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(10)]
             for k in range(10):
@@ -37,7 +41,7 @@ for shape in shapes:
             torch.cuda.synchronize()
             stg = np.array([[ev[k][i].elapsed_time(ev[k][i + 1]) for i in range(len(names))] for k in range(10)]).mean(axis=0)
             p = st._a0 or {}
-            out.append('%s planes %s: %.3f ms (%s%s%s; %s)' % ('padded' if pad else 'caller\'s', (st.ny, st.nz), e0.elapsed_time(e1) / 30,
+            out.append('%s planes %s: median %.3f ms, mean %.3f, max %.3f (%s%s%s; %s)' % ('padded' if pad else 'caller\'s', (st.ny, st.nz), np.median(per), per.mean(), per.max(),
                                                               st.axis0_mode, ', dots' if p.get('dots') else '', ', fused' if p.get('fused') else '',
                                                               ' '.join('%.3f' % v for v in stg)))
             del st, T
