@@ -604,6 +604,7 @@ def main(argv=None):
         T = adi.DeviceField(torch.rand(shape, dtype=torch.float64, device=dev, generator=gen) * 980.0 + 20.0)
 
     stage_names = ['explicit', 'sweep_axis0', 'sweep_axis1', 'sweep_axis2_contig']
+    parity_1d = None
     if not multi:
         grid = adi.Grid3D(n, n, n, dx, mask)
         packs = adi.precompute_coeff_packs_unified(grid, mat, robin_h=500.0)
@@ -621,8 +622,7 @@ def main(argv=None):
         # the ranks (BASELINE.json configs[2]; the strong-scaling workload itself); (2) with weak scaling also this job's own slab
         # thickness -- n planes per rank, hence the interface form of the timed loop -- on a grid of reduced lateral extent
         # (W*n x 128 x 128), which rank 0 can step on one domain in milliseconds.
-        parity_1d = None
-        if world > 1:
+        if world > 1 or (force_dist and not rehearse):      # (--force-dist: the same calls over a one-rank RCCL group, a plumbing check)
             from adi_thermal_fields_amd.dist_slab import split_planes as _split
             parity_1d = parity_vs_one_domain(a, adi, dist_slab, dist, world, rank, mat, prm, dx, Tinf, make_comm, staged,
                                              _split(n, world), n, n, '%d^3 cut into slabs over the %d ranks (strong split)' % (n, world))
@@ -756,7 +756,7 @@ def main(argv=None):
                       unit='GB/s', frac=kernels[dom]['frac'], traffic=traffic),
         kernels=kernels,
         **({'ranks': ranks_info} if ranks_info is not None else {}),
-        **({'parity_vs_one_domain': parity_1d} if (multi and world > 1) else {}),
+        **({'parity_vs_one_domain': parity_1d} if parity_1d is not None else {}),
     )
     if xs is not None:
         line['general_pack_sweeps_42B'] = xs

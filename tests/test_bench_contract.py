@@ -90,3 +90,12 @@ def test_two_real_ranks_line_proves_itself_against_one_domain(scaling):
     r = d['ranks']
     assert r['world_size_from_process_group'] == 2 and 'gloo-staged' in r['transport'] and len(r['loop_seconds_per_rank']) == 2
     assert d['comm_overlap']['selfcheck_rel_diff'] <= 1e-12
+
+
+def test_single_rank_rccl_line_runs_the_parity_calls_over_nccl():
+    """--force-dist: the slab path over a one-rank RCCL process group; the calls of parity_vs_one_domain (gather, object
+    all-gather, the one-domain leg) go through the real `nccl` backend here, the only place a one-GPU box can exercise them"""
+    d = _bench('--n', '128', '--steps', '3', '--warmup', '2', '--no-cpu', '--force-dist')
+    p = d['parity_vs_one_domain']
+    assert p['ok'] is True and p['rel_linf'] <= 1e-12 and p['planes_per_rank'] == [128]
+    assert d['ranks']['backend'] == 'nccl' and d['ranks']['world_size_from_process_group'] == 1
