@@ -69,16 +69,30 @@ def split_planes(nx, world):
 
 # ------------------------------------------------------------------------------------------- comm
 class TorchDistComm:
-    """torch.distributed (nccl = RCCL on ROCm, or gloo on CPU)."""
+    """torch.distributed (nccl = RCCL on ROCm, or gloo on CPU).
 
-    def __init__(self, group=None):
+    all_gather_mode: how the all-gather of the interface forms that need every rank's planes ('exact', 'deferred_exact': thin
+    slabs, strong scaling) travels.  'collective' = `all_gather_into_tensor` (RCCL picks its algorithm, ring-like on most
+    topologies: world-1 steps, each bound by ONE link); 'mesh' = every rank sends its block to every other rank in one batch of
+    point-to-point operations -- on an xGMI node every pair of GPUs has a link of its own (7 x ~153 GB/s per GPU), so the
+    world-1 blocks leave over world-1 links at once; 'auto' (default) = measured: the first time a payload of a size class
+    (>= 256 KiB, device tensors, nccl, world >= 3) comes by, both are timed on the spot (a few iterations each, the slower rank
+    counts) and the faster one is kept for that size class.  The choice is collective -- it comes out of an all-reduce -- and is
+    reported by bench.py in `ranks.all_gather`; nothing here has run on more than one GPU, which is why it is measured, not
+    assumed."""
+
+    def __init__(self, group=None, all_gather_mode='auto'):
         import torch.distributed as dist
+        assert all_gather_mode in ('auto', 'collective', 'mesh')
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.bytes_sent = 0          # payload this rank has handed to the transport (bench.py reports it per step)
         self.n_exchanges = 0
+        self.all_gather_mode = all_gather_mode
+        self.tune_min_bytes, self.tune_any_backend = 256 << 10, False        # (tests lower / set these to walk the measuring path on gloo)
+        self.all_gather_choice = {}  # size class (bytes, rounded up to a power of two) -> dict(mode, collective_ms, mesh_ms)
 
     def exchange_planes(self, send_lo, send_hi, recv_lo, recv_hi):
         """send_lo -> rank-1 (received there as recv_hi), send_hi -> rank+1 (received there as recv_lo)."""
@@ -97,9 +111,66 @@ class TorchDistComm:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
 
+    def _all_gather_mesh(self, out, inp):
+        """every block straight to every peer: world-1 sends and world-1 receives in ONE batch"""
+        dist, n = self.dist, inp.numel()
+        flat, src = out.view(-1), inp.reshape(-1)
+        flat[self.rank * n:(self.rank + 1) * n].copy_(src)
+        ops = []
+        for d in range(1, self.world):                 # peers in rotated order: no two ranks start on the same target
+            r = (self.rank + d) % self.world
+            ops.append(dist.P2POp(dist.isend, src, r, self.group))
+        for d in range(1, self.world):
+            r = (self.rank - d) % self.world
+            ops.append(dist.P2POp(dist.irecv, flat[r * n:(r + 1) * n], r, self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def _all_gather_pick(self, out, inp):
+        """'collective' or 'mesh' for this payload (see the class docstring); measured once per size class when 'auto'"""
+        if self.all_gather_mode != 'auto':
+            return self.all_gather_mode
+        nbytes = inp.numel() * inp.element_size()
+        on_rccl = inp.is_cuda and self.dist.get_backend(self.group) == 'nccl'
+        if nbytes < self.tune_min_bytes or self.world < 3 or not (on_rccl or self.tune_any_backend):
+            return 'collective'
+        cls = 1 << (nbytes - 1).bit_length()
+        got = self.all_gather_choice.get(cls)
+        if got is None:
+            dist = self.dist
+            times = []
+            for fn in (lambda: dist.all_gather_into_tensor(out, inp, group=self.group), lambda: self._all_gather_mesh(out, inp)):
+                for _ in range(2):
+                    fn()
+                if inp.is_cuda:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.current_stream().synchronize()
+                    dist.barrier(group=self.group)
+                    e0.record()
+                    for _ in range(5):
+                        fn()
+                    e1.record(); e1.synchronize()
+                    times.append(e0.elapsed_time(e1) / 5.0)
+                else:
+                    import time
+                    dist.barrier(group=self.group)
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        fn()
+                    times.append((time.perf_counter() - t0) * 1e3 / 5.0)
+            t = torch.tensor(times, dtype=torch.float64, device=inp.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)          # the slowest rank counts; the same on every rank
+            tc, tm = float(t[0]), float(t[1])
+            got = self.all_gather_choice[cls] = dict(mode='mesh' if tm < 0.9 * tc else 'collective', collective_ms=round(tc, 4),
+                                                     mesh_ms=round(tm, 4))
+        return got['mode']
+
     def all_gather(self, out, inp):
         self.bytes_sent += inp.numel() * inp.element_size() * (self.world - 1)
-        self.dist.all_gather_into_tensor(out, inp, group=self.group)
+        if self._all_gather_pick(out, inp) == 'mesh':
+            self._all_gather_mesh(out, inp)
+        else:
+            self.dist.all_gather_into_tensor(out, inp, group=self.group)
 
 
 class HostStagedDistComm(TorchDistComm):

@@ -691,6 +691,8 @@ def main(argv=None):
                           exchanges_per_rank_total=[int(v) for v in allr[:, nst + 1]],
                           transport=('gloo-staged (TEST transport: every rank on cuda:0, payloads through pinned host memory; '
                                      'not a multi-GPU measurement)' if staged else 'nccl (RCCL)'),
+                          # collective or point-to-point mesh all-gather, as measured on this node per payload size (dist_slab.TorchDistComm)
+                          all_gather={str(k): v for k, v in getattr(comm, 'all_gather_choice', {}).items()},
                           note='byte / exchange counters cover %d steps (warm-up, self-check and timed loop)' % nsteps_counted)
     if rank != 0:
         if world > 1:

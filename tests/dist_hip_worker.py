@@ -34,6 +34,7 @@ CASES = [
     ('solid box, thin slabs, stiff',  16,   200.0, dict(solid=True, end_rows=True), 3, 'deferred_exact'),
     ('voids, uneven slabs',           'uneven', 0.05, {}, 3, None),
     ('solid box, uneven thin slabs',  'uneven16', 200.0, dict(solid=True, end_rows=True), 2, None),
+    ('solid box, thin slabs, mesh all-gather', 16, 200.0, dict(solid=True, end_rows=True, mesh=True), 2, 'deferred_exact'),
 ]
 
 
@@ -85,7 +86,8 @@ def main():
             robin = rng.uniform(100.0, 900.0, shape)
         bc = dict(robin_h=robin, neumann={'x+': 2e5})
         bc_local = dict(bc, robin_h=(np.ascontiguousarray(robin[i0:i1]) if isinstance(robin, np.ndarray) else robin))
-        comm = dist_slab.HostStagedDistComm() if staged else dist_slab.TorchDistComm()
+        comm = dist_slab.HostStagedDistComm() if staged else \
+            dist_slab.TorchDistComm(all_gather_mode='mesh' if opts.get('mesh') else 'auto')     # (auto: measured on the spot)
         st = dist_slab.SlabStepper(mask[i0:i1], dx, mat, prm, 20.0, comm=comm, **bc_local)
         st._allow_dots = opts.get('allow_dots', True); st._force_exact = opts.get('force_exact', False)
         st._allow_deferred_lines = opts.get('allow_deferred_lines', True)

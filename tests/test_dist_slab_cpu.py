@@ -109,8 +109,11 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q, opts=None):
         st = dist_slab.SlabStepper(c['mask'][i0:i1], c['dx'], orc.Material(**c['mat']),
                                    orc.Params(c['dt'], c['theta']), c['Tinf'], dir_mask=loc(c['dir_mask']),
                                    dir_value=loc(c['dir_value']), neumann=neumann, robin_h=robin_h,
-                                   comm=(dist_slab.HostStagedDistComm() if opts.get('staged') else dist_slab.TorchDistComm()),
+                                   comm=(dist_slab.HostStagedDistComm() if opts.get('staged') else
+                                         dist_slab.TorchDistComm(all_gather_mode=opts.get('all_gather_mode', 'auto'))),
                                    engine=engine)
+        if opts.get('tune_all_gather'):    # walk the measuring path of all_gather_mode='auto' on CPU ranks (product: nccl only)
+            st.comm.tune_min_bytes, st.comm.tune_any_backend = 512, True
         assert st._padded == bool(opts.get('pad'))
         st._force_exact = bool(opts.get('force_exact', False))
         st._allow_window = bool(opts.get('allow_window', True))
@@ -134,6 +137,11 @@ def _worker(rank, world, port, case_name, sizes, nsteps, q, opts=None):
             modes_seen.append((st.axis0_mode, bool((st._a0 or {}).get('quick'))))
         if opts.get('dt_seq'):
             q.put((rank, T.numpy().copy(), tuple(modes_seen)))
+            return
+        if opts.get('tune_all_gather'):
+            ch = st.comm.all_gather_choice
+            assert ch and all(v['mode'] in ('mesh', 'collective') and v['collective_ms'] > 0 and v['mesh_ms'] > 0 for v in ch.values()), ch
+            q.put((rank, T.numpy().copy(), tuple(sorted((k, v['mode']) for k, v in ch.items()))))
             return
         if opts.get('staged'):             # ... and the gather bench.py / tests/dist_hip_worker.py use: the whole field on rank 0
             full = dist_slab.gather_slabs(T, sizes, host_staged=True)
@@ -420,6 +428,37 @@ def test_short_lived_plans_are_made_without_measuring(world, sizes):
     got2, modes2 = _run_world(world, name, sizes, len(seq), dict(dt_seq=seq, quick_replan=False))
     assert not any(qk for _, qk in list(modes2)[0])
     assert rel_linf(got2, T) <= 1e-12
+
+
+@pytest.mark.parametrize('world,name,sizes,opts', [
+    (3, 'stiff:72', [24, 24, 24], dict(force_exact=True, all_gather_mode='mesh')),                  # the two-pass all-gather form
+    (4, 'solid:64:200', [16] * 4, dict(all_gather_mode='mesh')),                                     # deferred_exact: thin slabs, no decay
+    (2, 'stiff:64', [32, 32], dict(force_exact=True, all_gather_mode='mesh', prefetch=True)),
+])
+def test_mesh_all_gather_matches_the_collective(world, name, sizes, opts):
+    """TorchDistComm(all_gather_mode='mesh'): every block straight to every peer in one batch of point-to-point operations
+    (what an xGMI node's pairwise links are for) instead of the collective -- same fields, on CPU ranks over gloo"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import adi_oracle as orc
+    from helpers import run_cart_case, rel_linf
+    c = _case(name)
+    got, modes = _run_world(world, name, sizes, c['nsteps'], opts)
+    assert modes <= {'exact', 'deferred_exact'}, modes
+    got2, _ = _run_world(world, name, sizes, c['nsteps'], dict(opts, all_gather_mode='collective'))
+    assert np.array_equal(got, got2)                                 # the transport does not touch the numbers
+    assert rel_linf(got, run_cart_case(orc, c)['T_final']) <= 1e-12
+
+
+def test_all_gather_choice_is_measured_and_collective():
+    """all_gather_mode='auto': the first payload of a size class is timed both ways (collective, point-to-point mesh), the
+    slowest rank counts, every rank ends with the same choice -- walked on CPU ranks over gloo (the product measures on nccl only)"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import adi_oracle as orc
+    from helpers import run_cart_case, rel_linf
+    c = _case('stiff:72')
+    got, choices = _run_world(3, 'stiff:72', [24, 24, 24], c['nsteps'], dict(force_exact=True, tune_all_gather=True))
+    assert len(choices) == 1, choices                       # the same table on every rank
+    assert rel_linf(got, run_cart_case(orc, c)['T_final']) <= 1e-12
 
 
 def test_deferred_form_with_per_line_solutions_is_decided_collectively_on_one_plane_slabs():
