@@ -400,6 +400,41 @@ def test_deferred_lines_with_the_cost_rule_on_a_part_with_cavities(world, name, 
     assert np.array_equal(got[~c['mask']], c['T0'][~c['mask']])
 
 
+def test_decay_bound_behind_the_quick_plans():
+    """what SlabStepper._quick_plan relies on: the coupling THROUGH k rows of a sharded-axis line -- tg * |(A^-1)[0, k-1]|, what
+    the condensed entries cF / aL are made of -- is at most rho^k, rho the per-row factor of solid interior rows
+    (-tg, 1 + 2 tg, -tg), whatever the rows are: interior rows with a Robin / Neumann-free diagonal >= 1 + 2 tg, rows that lack a
+    neighbour (line start / end: the off-diagonal is 0), Dirichlet cells (identity rows).  Random lines, dense inverses."""
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for trial in range(400):
+        tg = float(10.0 ** rng.uniform(-2.0, 3.5))
+        k = int(rng.integers(2, 40))
+        rho = 2.0 * tg / (1.0 + 2.0 * tg + np.sqrt(1.0 + 4.0 * tg))
+        kind = rng.choice(4, size=k, p=[0.7, 0.15, 0.1, 0.05]) if trial % 3 else np.zeros(k, dtype=int)
+        A = np.zeros((k, k))
+        for i in range(k):
+            lo = i > 0 and kind[i] != 2 and kind[i] != 3 and kind[i - 1] != 3 and not (kind[i - 1] == 2 and rng.random() < 0.5)
+            hi = i + 1 < k and kind[i] != 3 and kind[i + 1] != 3 and not (kind[i] == 2)
+            if kind[i] == 3:                                   # Dirichlet cell: identity row
+                A[i, i] = 1.0
+                continue
+            nnb = (1 if (lo or i == 0) else 0) + (1 if (hi or i == k - 1) else 0)     # the block's ends couple to the outside
+            A[i, i] = 1.0 + tg * nnb + (float(rng.uniform(0.0, 3.0)) if kind[i] == 1 else 0.0)
+            if lo:
+                A[i, i - 1] = -tg
+            if hi:
+                A[i, i + 1] = -tg
+        for i in range(k - 1):                                  # a neighbour relation holds both ways: coupling only if both rows have it
+            if A[i, i + 1] == 0.0 or A[i + 1, i] == 0.0:
+                A[i, i + 1] = A[i + 1, i] = 0.0
+        Ai = np.linalg.inv(A)
+        c = tg * max(abs(Ai[0, k - 1]), abs(Ai[k - 1, 0]))
+        worst = max(worst, c / rho ** k)
+        assert c <= rho ** k * (1.0 + 1e-9) + 1e-300, (trial, tg, k, c, rho ** k)
+    assert 0.5 < worst <= 1.0 + 1e-9, worst                    # ... and the bound is attained (uniform rows, small tg)
+
+
 @pytest.mark.parametrize('world,sizes', [(2, [32, 32]), (3, [22, 20, 22])])
 def test_short_lived_plans_are_made_without_measuring(world, sizes):
     """an event loop changes the time step (and the mask) from step to step; after the first plan SlabStepper re-plans from the
