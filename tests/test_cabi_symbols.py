@@ -33,6 +33,13 @@ def test_argument_errors_without_gpu():
     with pytest.raises(ValueError):
         _lib.check(_lib.lib.adi_sweep(5, 0, None, None, None, None, None, None, 1, 1, 1, 0, 0, 0.5, 1.0, 1.0, 0.0,
                                       None, None, None, None, None, 0, None))
+    with pytest.raises(ValueError, match='adi_deferred_lines_apply'):          # K > nx
+        _lib.check(_lib.lib.adi_deferred_lines_apply(ctypes.c_void_p(8), 4, 64, 64, ctypes.c_void_p(8), 3, ctypes.c_void_p(8), 5,
+                                                     ctypes.c_void_p(8), 0, None))
+    with pytest.raises(ValueError, match='lower boundary without its weights'):
+        _lib.check(_lib.lib.adi_interface_deferred_lines(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), None, None, None,
+                                                         None, None, 16, ctypes.c_void_p(8), ctypes.c_void_p(8), None, None, None, None,
+                                                         None))
     with pytest.raises(ValueError, match='unknown zbc.kind_bot'):
         h = ctypes.c_void_p()
         _lib.check(_lib.lib.adi_cyl_plan_create(4, 4, 4, 0, 1e-3, 0.1, 1e-3, 1.0, 1.0, 1.0, 0.1, 0.0, 0.0, 7, 0,
