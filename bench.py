@@ -319,12 +319,21 @@ def quiet_gc():
     gc.disable()
 
 
+def make_events(k):
+    """k timing events that already exist on the device: torch creates the HIP event at the first record(), a few microseconds
+    each -- hundreds of them inside a 30 ms timed region are a measurable part of it.  Recorded once here, re-recorded in the loop."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(k)]
+    for e in ev:
+        e.record()
+    return ev
+
+
 def timed_steps(step_fn, nstages, steps=20, warmup=5, every=1):
     """`steps` calls of step_fn(events or None) after `warmup` untimed ones: (ms per step between two events around the whole
     loop, per-stage mean ms from events recorded on every `every`-th step -- small kernels notice their own event records)"""
     quiet_gc()             # BEFORE the warm-up: a collection takes 0.1 s or more of host time, the GPU idles and clocks down, and the
-    evs = {s_: [torch.cuda.Event(enable_timing=True) for _ in range(nstages + 1)] for s_ in range(steps) if s_ % every == 0}
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = {s_: make_events(nstages + 1) for s_ in range(steps) if s_ % every == 0}
+    e0, e1 = make_events(2)
     for _ in range(warmup):    # first steps after it run slow; the warm-up must flow straight into the timed loop
         step_fn(None)
     torch.cuda.synchronize()
@@ -450,7 +459,7 @@ def main_cyl(a):
     # the three kernels take ~45 us each, an event record a few: per-sweep events on every 4th step of the timed region
     # only (the others run the same launches without them), so that the events do not set the step time they measure
     sampled = [s_ for s_ in range(a.steps) if s_ % 4 == 0]
-    ev = {s_: [torch.cuda.Event(enable_timing=True) for _ in range(4)] for s_ in sampled}
+    ev = {s_: make_events(4) for s_ in sampled}
     quiet_gc()             # before the warm-up, which must flow straight into the timed loop (see timed_steps)
     for _ in range(a.warmup):
         st._step_inplace(X)
@@ -676,7 +685,7 @@ def main(argv=None):
             T = stepper.step(T, **kw)                      # the plan (and with it the stage list) exists after one step
         stage_names = stepper.stage_names                  # depends on the axis-0 plan chosen for this dt / mask
     nst = len(stage_names)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(a.steps)]
+    ev = [make_events(nst + 1) for _ in range(a.steps)]
     sync()
     t0 = time.perf_counter()
     for s in range(a.steps):
