@@ -427,7 +427,8 @@ def main_cyl(a):
     the coefficients are per-index constants).  N > 1: independent replicas (the path does not shard)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    staged = a.transport == 'gloo-staged' and world > 1      # TEST transport: every replica on cuda:0
+    local_rank = 0 if staged else int(os.environ.get('LOCAL_RANK', '0'))
     assert world == a.gpus, 'WORLD_SIZE (%d) != --gpus (%d)' % (world, a.gpus)
     need_gpu(rank)
     torch.cuda.set_device(local_rank)
@@ -436,7 +437,12 @@ def main_cyl(a):
     if world > 1:
         import datetime
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=a.pg_timeout))
+        tmo = datetime.timedelta(seconds=a.pg_timeout)
+        if staged:
+            dist.init_process_group('gloo', timeout=tmo)
+        else:
+            dist.init_process_group('nccl', device_id=dev, timeout=tmo)
+    col = Collect(dist, world > 1, staged, dev)
     import adi_thermal_fields_amd.adi3d_hip_cyl as cyl
     nr, nphi, nz = 128, 256, 512
     g = cyl.GridCyl(nr, nphi, nz, 2.5e-4, 2 * np.pi / nphi, 2.5e-4, 0.032)
@@ -449,8 +455,7 @@ def main_cyl(a):
     st = cyl.StagedCylStepper(g, mat, prm, rr, zbc)
 
     def sync():
-        if world > 1:
-            dist.barrier()
+        col.barrier()
         torch.cuda.synchronize()
     # The nsub loop of a driver on a resident field (StagedCylStepper.run): the loop owns its field, so the three sweeps
     # run IN PLACE -- every sweep kernel reads only the rows it writes -- and the working set is one 134 MB field, inside
@@ -470,10 +475,7 @@ def main_cyl(a):
     sync()
     gc.enable()
     T = cyl.DeviceField(X)
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = elapsed.item()
+    elapsed = col.max(time.perf_counter() - t0)
     assert bool(torch.isfinite(T.t).all().item())
     if rank != 0:
         dist.destroy_process_group()

@@ -99,3 +99,10 @@ def test_single_rank_rccl_line_runs_the_parity_calls_over_nccl():
     p = d['parity_vs_one_domain']
     assert p['ok'] is True and p['rel_linf'] <= 1e-12 and p['planes_per_rank'] == [128]
     assert d['ranks']['backend'] == 'nccl' and d['ranks']['world_size_from_process_group'] == 1
+
+
+def test_cylindrical_replicas_line():
+    """`bench.py --config cyl --gpus 2`: the cylindrical path does not shard -- N independent replicas, the
+    barrier and max-over-ranks timing of the contract; two real processes on the one GPU over the gloo-staged test transport"""
+    d = _bench('--config', 'cyl', '--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu', '--transport', 'gloo-staged')
+    assert d['n_gpus'] == 2 and d['config']['decomposition'] == 'replicas only' and d['metric'].startswith('adi_cyl')
