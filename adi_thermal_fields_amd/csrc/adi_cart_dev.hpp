@@ -75,6 +75,8 @@ struct SweepScal {
     // differs from that by the two interface values of the line times the decaying homogeneous solutions c_w.
     // c_lo / c_hi: dense (ny, nz) planes (null: no neighbour on that side); c_w: c_n weights, exactly 0 beyond their reach.
     const double *c_lo = nullptr, *c_hi = nullptr, *c_w = nullptr;
+    const double *c_u2 = nullptr;   // (c_lo, c_hi) interleaved per line (adi_sweep_corrected's scratch): planes within reach of BOTH
+                                    // interfaces fetch the pair with one 16-byte load
     int c_n = 0;
     unsigned c_bytes = 0;   // bytes of a correction plane (the range of the buffer descriptors over c_lo / c_hi)
     // (Lines that are not uniform: their own weights are applied in memory by adi_deferred_lines_apply before this sweep, and
@@ -440,6 +442,7 @@ __device__ __forceinline__ void tile_separators(double *sm, int tid, int kk, int
 // arithmetic in the VALU (measured: half of the fused kernel's VALU instructions); here the row offsets live in
 // scalar registers and one per-thread offset serves every load.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
@@ -481,11 +484,26 @@ __device__ __forceinline__ double2 corr_weights(const SweepScal &s, long to)
     }
     return w;
 }
-template <int M>
+// PAIR: the build carries the one-load-for-both-planes path (the FAST kernels; the GENERAL kernels sit at their register budget and
+// serve ragged tiles and queued units only: they keep the two-load form, same bits)
+template <int M, bool PAIR = true>
 __device__ __forceinline__ void corr_apply(const SweepScal &s, double2 w, long to, unsigned off8, unsigned st8, double (&d)[M],
                                            bool inside)
 {
     (void)to;
+    if (PAIR && s.c_u2 != nullptr && w.x != 0.0 && w.y != 0.0) {
+        // both interfaces reach this plane: one 16-byte load per row instead of two 8-byte ones (L2 hits either way, and the
+        // strided kernels are bound by the number of vector-memory instructions); lo first, then hi: the bits of the two-load form
+        const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)s.c_u2, 0, (int)(2u * s.c_bytes), 0x00020000);
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            const unsigned vo = inside ? 2u * off8 : 2u * (off8 + (unsigned)r * st8), so = inside ? 2u * (unsigned)r * st8 : 0u;
+            const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rU, vo, so, 0);
+            d[r] = __builtin_fma(w.x, __hiloint2double((int)q[1], (int)q[0]), d[r]);
+            d[r] = __builtin_fma(w.y, __hiloint2double((int)q[3], (int)q[2]), d[r]);
+        }
+        return;
+    }
     if (w.x != 0.0) {
         const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc((void *)s.c_lo, 0, (int)s.c_bytes, 0x00020000);
         if (inside) {                  // every row of the tile lies inside the plane: scalar row offsets (0.02 ms at 512^3)

@@ -528,13 +528,15 @@ __global__ __launch_bounds__(256) void k_interface_deferred_lines(
 // coalesced.  The same fma as corr_apply: a line gives the same bits whichever way its correction is applied.
 __global__ __launch_bounds__(256) void k_deferred_lines_apply(double *__restrict__ x, int nx, long sx, const int *__restrict__ cells,
                                                               long nflag, const double *__restrict__ wc, int K,
-                                                              const double *__restrict__ u, int from_hi)
+                                                              const double *__restrict__ u, int from_hi,
+                                                              const int *__restrict__ nrows)
 {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nflag) return;
     const long cell = cells[q];
     const double uu = u[cell];
-    for (int r = blockIdx.y; r < K; r += gridDim.y) {
+    const int Kq = (nrows != nullptr && nrows[q] < K) ? nrows[q] : K;     // rows beyond carry exact zeros: not read
+    for (int r = blockIdx.y; r < Kq; r += gridDim.y) {
         // a flagged line's weights are exact zeros beyond its first row outside the mask (identity rows cut the coupling): a
         // line through a cavity 150 planes from the interface carries 150 weights, not K; x + 0 * u = x is skipped unread
         const double w = wc[(long)r * nflag + q];
@@ -688,7 +690,7 @@ int adi_interface_deferred_lines(const double *d_first, const double *d_last, co
 }
 
 int adi_deferred_lines_apply(double *d_x, int nx, long plane_stride, long plane_cells, const int *d_cells, long nflag,
-                             const double *d_wc, int K, const double *d_u, int from_high_end, void *stream)
+                             const double *d_wc, int K, const double *d_u, int from_high_end, const int *d_nrows, void *stream)
 {
     ADI_REQUIRE(d_x && d_u && nx > 0 && plane_cells > 0 && plane_stride >= plane_cells && K >= 0 && K <= nx && nflag >= 0,
                 "adi_deferred_lines_apply: bad argument");
@@ -696,7 +698,7 @@ int adi_deferred_lines_apply(double *d_x, int nx, long plane_stride, long plane_
     ADI_REQUIRE(d_cells && d_wc, "adi_deferred_lines_apply: flagged lines without their cells / weights");
     const unsigned gy = (unsigned)(K < 64 ? K : 64);
     hipLaunchKernelGGL(k_deferred_lines_apply, dim3((unsigned)((nflag + 255) / 256), gy), dim3(256), 0, as_stream(stream), d_x, nx,
-                       plane_stride, d_cells, nflag, d_wc, K, d_u, from_high_end);
+                       plane_stride, d_cells, nflag, d_wc, K, d_u, from_high_end, d_nrows);
     ADI_CHECK_LAUNCH();
     return ADI_OK;
 }

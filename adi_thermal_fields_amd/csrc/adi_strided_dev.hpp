@@ -118,7 +118,6 @@ __device__ __forceinline__ void load_segment_raw(
 // its M rows packed four per register.  Replaces M single-byte loads per thread: the strided kernels are bound by the
 // issue rate of the vector-memory pipe, not by bytes (SQ_WAIT_INST_ANY, profiles/r02_*).  `bt`: the tile's first byte
 // of row 0 of the line (16-byte aligned rows: host / block-uniform check); voff_row0: r0*stride (elements), kk = lane & 15.
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int M>
 __device__ __forceinline__ void load_bytes_packed16(const uint8_t *bt, unsigned voff_row0, unsigned stride, int kk, uint8_t *strip,
                                                     unsigned (&w)[M / 4])

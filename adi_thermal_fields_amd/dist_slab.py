@@ -365,6 +365,7 @@ class HipEngine:
         self.hip, self._lib, self.lib, self.check = hip, _lib, _lib.lib, _lib.check
         self.device = hip._device()
         self.box_hint = 0          # 2: every cell of every slab is in the mask (SlabStepper.set_mask decides, collectively)
+        self._u2 = {}              # (ny, nz) -> scratch of adi_sweep_corrected: the two interface planes interleaved
         self.mask_epoch = 0        # bumped by SlabStepper.set_mask: the flags / packs are rebuilt in place
         self._nofb = {}            # no-fallback promise per sweep configuration (bit 2 of `sparse`, include/adi_hip.h)
         self._fconsts = {}         # coefficient storage -> per-face scalars of the pack built on it (h_face_consts)
@@ -572,7 +573,13 @@ class HipEngine:
         key, bit = self._promise('sweep', 1, variant, Li, flags, pack)
         a = list(self._args(1, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf))
         a[12] |= bit
-        self.check(self.lib.adi_sweep_corrected(*a[1:], h._p(t_out), h._p(ulo), h._p(uhi), h._p(w_corr), self._fc(pack),
+        # both interface planes: the library interleaves them into a scratch of (ny, nz) pairs and the sweep fetches both with one load
+        u2 = None
+        if ulo is not None and uhi is not None:
+            u2 = self._u2.get((Li.ny, Li.nz))
+            if u2 is None:
+                u2 = self._u2[(Li.ny, Li.nz)] = torch.zeros(2 * Li.ny * Li.nz, dtype=torch.float64, device=self.device)
+        self.check(self.lib.adi_sweep_corrected(*a[1:], h._p(t_out), h._p(ulo), h._p(uhi), h._p(w_corr), h._p(u2), self._fc(pack),
                                                 h._p(w), w.numel(), self._sp()))
         self._learn(key, w)
 
@@ -607,13 +614,14 @@ class HipEngine:
                                                          h._p(om.get('lo_next')), nlines, h._p(ulo), h._p(uhi), h._p(uni_lo),
                                                          h._p(uni_hi), h._p(ulo_uni), h._p(uhi_uni), self._sp()))
 
-    def deferred_lines_apply(self, Li, x, cells, wc, u, from_high_end):
-        """x[i][cells[q]] += wc[r][q] * u[cells[q]], i = r or nx-1-r: the flagged lines of one side get their own weights"""
+    def deferred_lines_apply(self, Li, x, cells, wc, u, from_high_end, nrows=None):
+        """x[i][cells[q]] += wc[r][q] * u[cells[q]], i = r or nx-1-r: the flagged lines of one side get their own weights
+        (nrows[q]: rows of line q that can carry a non-zero weight; the rest is not read)"""
         h = self.hip
         if cells.numel() == 0:
             return
         self.check(self.lib.adi_deferred_lines_apply(h._p(x), Li.nx, Li.sx, Li.ny * Li.nz, h._p(cells), cells.numel(), h._p(wc),
-                                                     int(wc.shape[0]), h._p(u), 1 if from_high_end else 0, self._sp()))
+                                                     int(wc.shape[0]), h._p(u), 1 if from_high_end else 0, h._p(nrows), self._sp()))
 
 
     def condense0_fused(self, variant, L, T_ext, i0, j0, flags, pack, dx, dt, kappa, theta, Tinf, cond, r0_out=None):
@@ -1264,7 +1272,11 @@ class SlabStepper:
             off = ((fr & 1) == 0).all(dim=0)
             cells = (~(uni | off)).reshape(-1).nonzero().reshape(-1)
             wc = Wr.reshape(Wr.shape[0], -1).index_select(1, cells).contiguous()
-            return uni.reshape(-1).to(torch.uint8).contiguous(), cells.to(torch.int32).contiguous(), wc
+            # rows of each flagged line that can carry a non-zero weight: everything beyond its first row outside the mask is an
+            # exact zero (identity rows cut the coupling) and need not even be read
+            rows = torch.arange(1, wc.shape[0] + 1, device=wc.device, dtype=torch.int32).reshape(-1, 1)
+            nrows = ((wc != 0).to(torch.int32) * rows).amax(dim=0).to(torch.int32).contiguous() if cells.numel() else cells.to(torch.int32)
+            return uni.reshape(-1).to(torch.uint8).contiguous(), cells.to(torch.int32).contiguous(), wc, nrows
         nflag = 0
         if ok and not first:
             W = E.homogeneous_solution(self.variant, self.Lint, fl, pk, prm.theta, gam, prm.dt, True)
@@ -1536,9 +1548,9 @@ class SlabStepper:
                                                plan['uhi'], sd['lo'][0] if 'lo' in sd else None, sd['hi'][0] if 'hi' in sd else None,
                                                plan['ulo_uni'], plan['uhi_uni'])
                     if 'lo' in sd:
-                        E.deferred_lines_apply(Li, Bi, sd['lo'][1], sd['lo'][2], plan['ulo'], False)
+                        E.deferred_lines_apply(Li, Bi, sd['lo'][1], sd['lo'][2], plan['ulo'], False, sd['lo'][3])
                     if 'hi' in sd:
-                        E.deferred_lines_apply(Li, Bi, sd['hi'][1], sd['hi'][2], plan['uhi'], True)
+                        E.deferred_lines_apply(Li, Bi, sd['hi'][1], sd['hi'][2], plan['uhi'], True, sd['hi'][3])
                 else:
                     E.interface_deferred(Bi[0], Bi[nl - 1], None if first else plan['prev_last'],
                                          None if last else plan['next_first'], plan['dfr']['omega'], self.nlines, plan['ulo'],

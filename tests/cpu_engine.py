@@ -228,7 +228,7 @@ class CpuEngine:
             x += w[::-1][:, None, None] * uhi.numpy().reshape(1, Li.ny, Li.nz)
         self.sweep(1, variant, Li, torch.from_numpy(x), flags, pack, theta, gam, dt, Tinf, t_out)
 
-    def deferred_lines_apply(self, Li, x, cells, wc, u, from_high_end):
+    def deferred_lines_apply(self, Li, x, cells, wc, u, from_high_end, nrows=None):
         """the flagged lines of one side get their own weights, in place (include/adi_hip.h, adi_deferred_lines_apply)"""
         if cells.numel() == 0:
             return
@@ -239,7 +239,10 @@ class CpuEngine:
         uu = u.numpy().reshape(-1)[c]
         rows = np.arange(K)
         planes = (Li.nx - 1 - rows) if from_high_end else rows
-        xv[planes[:, None], c[None, :]] += wc.numpy() * uu[None, :]
+        w = wc.numpy()
+        if nrows is not None:             # (rows beyond nrows[q] carry exact zeros: the product kernel does not read them)
+            assert not np.any(w * (np.arange(K)[:, None] >= nrows.numpy()[None, :]))
+        xv[planes[:, None], c[None, :]] += w * uu[None, :]
 
     # the deferred form with per-line homogeneous solutions (include/adi_hip.h, ABI v17), restated with dense solves
     def homogeneous_solution(self, variant, Li, flags, pack, theta, gam, dt, lower):

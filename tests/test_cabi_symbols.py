@@ -35,7 +35,7 @@ def test_argument_errors_without_gpu():
                                       None, None, None, None, None, 0, None))
     with pytest.raises(ValueError, match='adi_deferred_lines_apply'):          # K > nx
         _lib.check(_lib.lib.adi_deferred_lines_apply(ctypes.c_void_p(8), 4, 64, 64, ctypes.c_void_p(8), 3, ctypes.c_void_p(8), 5,
-                                                     ctypes.c_void_p(8), 0, None))
+                                                     ctypes.c_void_p(8), 0, None, None))
     with pytest.raises(ValueError, match='lower boundary without its weights'):
         _lib.check(_lib.lib.adi_interface_deferred_lines(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), None, None, None,
                                                          None, None, 16, ctypes.c_void_p(8), ctypes.c_void_p(8), None, None, None, None,
