@@ -89,7 +89,7 @@ SIGNATURES = {
     'adi_deferred_exact_coef': (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     'adi_sweep_corrected': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_long, c_int, c_double, c_double, c_double, c_double,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double_p, c_void_p, c_size_t,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_double_p, c_void_p, c_size_t,
                                     c_void_p]),
     'adi_interface_deferred_lines': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

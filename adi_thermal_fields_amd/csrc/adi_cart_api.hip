@@ -5,16 +5,6 @@
 
 using namespace adi;
 
-namespace adi {
-// (a[l], b[l]) -> out[2 l], out[2 l + 1]: the two interface planes of adi_sweep_corrected side by side (one 16-byte load per cell)
-__global__ __launch_bounds__(256) void k_interleave2(const double *__restrict__ a, const double *__restrict__ b, long n,
-                                                     double *__restrict__ out)
-{
-    const long l = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < n) reinterpret_cast<double2 *>(out)[l] = make_double2(a[l], b[l]);
-}
-}  // namespace adi
-
 extern "C" {
 
 long adi_recommended_plane_stride(int ny, int nz)
@@ -90,7 +80,7 @@ static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t 
                        long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
                        const double *d_xlo, const double *d_xhi, void *d_work, size_t work_bytes, void *stream,
                        const Fuse *fz, const double *fcs, const double *c_lo = nullptr, const double *c_hi = nullptr,
-                       const double *c_w = nullptr, const double *c_u2 = nullptr)
+                       const double *c_w = nullptr)
 {
     ADI_REQUIRE(axis >= 0 && axis < 3, "adi_sweep: bad axis %d", axis);
     bool has_dir, has_q;
@@ -118,7 +108,6 @@ static int sweep_entry(int axis, int variant, const double *d_in, const uint8_t 
         ADI_REQUIRE(axis == 1 && fz == nullptr && !d_xlo && !d_xhi, "adi_sweep_corrected: axis 1 sweeps only");
         ADI_REQUIRE((long)ny * nz * 8 < 0x7fffffffL, "adi_sweep_corrected: plane of %ld cells is too large", (long)ny * nz);
         s.c_lo = c_lo; s.c_hi = c_hi; s.c_w = c_w; s.c_n = nx; s.c_bytes = (unsigned)((long)ny * nz * 8);
-        s.c_u2 = (c_lo != nullptr && c_hi != nullptr && (long)ny * nz * 16 < 0x7fffffffL) ? c_u2 : nullptr;
     }
     hipStream_t st = as_stream(stream);
     SweepArgs a;
@@ -159,20 +148,13 @@ int adi_sweep(int axis, int variant, const double *d_in, const uint8_t *d_flags,
 int adi_sweep_corrected(int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
                         const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux, int nx, int ny, int nz,
                         long plane_stride, int sparse, double theta, double gam, double dt, double Tinf, double *d_out,
-                        const double *d_ulo, const double *d_uhi, const double *d_w, double *d_u2_scratch,
-                        const double *h_face_consts, void *d_work, size_t work_bytes, void *stream)
+                        const double *d_ulo, const double *d_uhi, const double *d_w, const double *h_face_consts, void *d_work,
+                        size_t work_bytes, void *stream)
 {
     ADI_REQUIRE(d_w != nullptr || (d_ulo == nullptr && d_uhi == nullptr), "adi_sweep_corrected: interface values without weights");
-    const double *u2 = nullptr;
-    if (d_u2_scratch != nullptr && d_ulo != nullptr && d_uhi != nullptr && d_w != nullptr && ny > 0 && nz > 0) {
-        const long nl = (long)ny * nz;
-        hipLaunchKernelGGL(k_interleave2, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, as_stream(stream), d_ulo, d_uhi, nl,
-                           d_u2_scratch);
-        u2 = d_u2_scratch;
-    }
     return sweep_entry(1, variant, d_in, d_flags, d_coeff, d_dir_mask, d_dir_val, d_qflux, nx, ny, nz, plane_stride,
                        sparse, theta, gam, dt, Tinf, d_out, nullptr, nullptr, d_work, work_bytes, stream, nullptr,
-                       h_face_consts, d_ulo, d_uhi, d_w, u2);
+                       h_face_consts, d_ulo, d_uhi, d_w);
 }
 
 static Fuse make_fuse(int nx, int ny, int nz, long plane_stride, double dx, double dt, double kappa, double theta,

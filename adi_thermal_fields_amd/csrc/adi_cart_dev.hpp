@@ -75,8 +75,6 @@ struct SweepScal {
     // differs from that by the two interface values of the line times the decaying homogeneous solutions c_w.
     // c_lo / c_hi: dense (ny, nz) planes (null: no neighbour on that side); c_w: c_n weights, exactly 0 beyond their reach.
     const double *c_lo = nullptr, *c_hi = nullptr, *c_w = nullptr;
-    const double *c_u2 = nullptr;   // (c_lo, c_hi) interleaved per line (adi_sweep_corrected's scratch): planes within reach of BOTH
-                                    // interfaces fetch the pair with one 16-byte load
     int c_n = 0;
     unsigned c_bytes = 0;   // bytes of a correction plane (the range of the buffer descriptors over c_lo / c_hi)
     // (Lines that are not uniform: their own weights are applied in memory by adi_deferred_lines_apply before this sweep, and
@@ -484,26 +482,14 @@ __device__ __forceinline__ double2 corr_weights(const SweepScal &s, long to)
     }
     return w;
 }
-// PAIR: the build carries the one-load-for-both-planes path (the FAST kernels; the GENERAL kernels sit at their register budget and
-// serve ragged tiles and queued units only: they keep the two-load form, same bits)
-template <int M, bool PAIR = true>
+// (Round 4 tried fetching both planes with ONE 16-byte load per row from an interleaved copy -- the strided kernels are bound by
+// the number of vector-memory instructions -- on the planes within reach of both interfaces: slower, not faster.  32 rows of
+// 16-byte results in flight took the axis-1 FAST kernel from 177 to 212 VGPRs and the corrected sweep from 0.51 to 0.58 ms.)
+template <int M>
 __device__ __forceinline__ void corr_apply(const SweepScal &s, double2 w, long to, unsigned off8, unsigned st8, double (&d)[M],
                                            bool inside)
 {
     (void)to;
-    if (PAIR && s.c_u2 != nullptr && w.x != 0.0 && w.y != 0.0) {
-        // both interfaces reach this plane: one 16-byte load per row instead of two 8-byte ones (L2 hits either way, and the
-        // strided kernels are bound by the number of vector-memory instructions); lo first, then hi: the bits of the two-load form
-        const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)s.c_u2, 0, (int)(2u * s.c_bytes), 0x00020000);
-#pragma unroll
-        for (int r = 0; r < M; ++r) {
-            const unsigned vo = inside ? 2u * off8 : 2u * (off8 + (unsigned)r * st8), so = inside ? 2u * (unsigned)r * st8 : 0u;
-            const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rU, vo, so, 0);
-            d[r] = __builtin_fma(w.x, __hiloint2double((int)q[1], (int)q[0]), d[r]);
-            d[r] = __builtin_fma(w.y, __hiloint2double((int)q[3], (int)q[2]), d[r]);
-        }
-        return;
-    }
     if (w.x != 0.0) {
         const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc((void *)s.c_lo, 0, (int)s.c_bytes, 0x00020000);
         if (inside) {                  // every row of the tile lies inside the plane: scalar row offsets (0.02 ms at 512^3)

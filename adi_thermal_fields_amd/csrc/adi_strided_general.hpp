@@ -78,7 +78,7 @@ __device__ __forceinline__ void strided_tile_general(
         if constexpr (!FUSE && CORR) {
             // deferred interface correction of a slab decomposition (SweepScal::c_*): block-uniform, off in ordinary sweeps
             if (s.c_w != nullptr)
-                corr_apply<M, false>(s, corr_weights(s, to), to, (voff + (unsigned)(ti * LINES)) * 8u, (unsigned)(g.stride * 8), R.vin,
+                corr_apply<M>(s, corr_weights(s, to), to, (voff + (unsigned)(ti * LINES)) * 8u, (unsigned)(g.stride * 8), R.vin,
                               Lp * M == g.n && (ti + 1) * LINES <= g.n_inner);
         }
 #pragma unroll

@@ -365,7 +365,6 @@ class HipEngine:
         self.hip, self._lib, self.lib, self.check = hip, _lib, _lib.lib, _lib.check
         self.device = hip._device()
         self.box_hint = 0          # 2: every cell of every slab is in the mask (SlabStepper.set_mask decides, collectively)
-        self._u2 = {}              # (ny, nz) -> scratch of adi_sweep_corrected: the two interface planes interleaved
         self.mask_epoch = 0        # bumped by SlabStepper.set_mask: the flags / packs are rebuilt in place
         self._nofb = {}            # no-fallback promise per sweep configuration (bit 2 of `sparse`, include/adi_hip.h)
         self._fconsts = {}         # coefficient storage -> per-face scalars of the pack built on it (h_face_consts)
@@ -573,13 +572,7 @@ class HipEngine:
         key, bit = self._promise('sweep', 1, variant, Li, flags, pack)
         a = list(self._args(1, variant, Li, t_in, flags, pack, theta, gam, dt, Tinf))
         a[12] |= bit
-        # both interface planes: the library interleaves them into a scratch of (ny, nz) pairs and the sweep fetches both with one load
-        u2 = None
-        if ulo is not None and uhi is not None:
-            u2 = self._u2.get((Li.ny, Li.nz))
-            if u2 is None:
-                u2 = self._u2[(Li.ny, Li.nz)] = torch.zeros(2 * Li.ny * Li.nz, dtype=torch.float64, device=self.device)
-        self.check(self.lib.adi_sweep_corrected(*a[1:], h._p(t_out), h._p(ulo), h._p(uhi), h._p(w_corr), h._p(u2), self._fc(pack),
+        self.check(self.lib.adi_sweep_corrected(*a[1:], h._p(t_out), h._p(ulo), h._p(uhi), h._p(w_corr), self._fc(pack),
                                                 h._p(w), w.numel(), self._sp()))
         self._learn(key, w)
 

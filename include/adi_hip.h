@@ -340,14 +340,11 @@ int adi_interface_deferred_lines(const double *d_first, const double *d_last, co
  * exact zeros beyond its first row outside the mask, and rows >= d_nrows[q] are not even read. */
 int adi_deferred_lines_apply(double *d_x, int nx, long plane_stride, long plane_cells, const int *d_cells, long nflag,
                              const double *d_wc, int K, const double *d_u, int from_high_end, const int *d_nrows, void *stream);
-/* d_u2_scratch (may be NULL): (ny*nz) pairs of doubles.  When both interface planes are given the entry point interleaves them
- * there -- (ulo, uhi) per line -- and the sweep fetches the pair with ONE 16-byte load on the planes within reach of both
- * interfaces (most of them at the bench's stiffness: 272 of 512) instead of two 8-byte ones; the results are the same bits. */
 int adi_sweep_corrected(int variant, const double *d_in, const uint8_t *d_flags, const double *d_coeff,
                         const uint8_t *d_dir_mask, const double *d_dir_val, const double *d_qflux,
                         int nx, int ny, int nz, long plane_stride, int sparse,
                         double theta, double gam, double dt, double Tinf,
-                        double *d_out, const double *d_ulo, const double *d_uhi, const double *d_w, double *d_u2_scratch,
+                        double *d_out, const double *d_ulo, const double *d_uhi, const double *d_w,
                         const double *h_face_consts, void *d_work, size_t work_bytes, void *stream);
 
 /*
