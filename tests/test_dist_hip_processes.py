@@ -1,4 +1,4 @@
-"""GPU (one is enough): several REAL processes drive HipEngine + SlabStepper.  Two / three fresh `torch.distributed.run`
+"""GPU (one is enough): several REAL processes drive HipEngine + SlabStepper.  Two / three / four fresh `torch.distributed.run`
 children, backend gloo, every rank on cuda:0, payloads staged through pinned host memory (dist_slab.HostStagedDistComm, a test
 transport), run every case of tests/dist_hip_worker.py -- each interface form, uneven slabs, thin slabs with per-line end rows
 -- against the one-domain HIP step: <= 1e-12.  What this covers that the other slab tests do not: separate processes with
@@ -7,7 +7,7 @@ ranks are threads of one context, the RCCL self-loop is one rank).  The real `nc
 tests/test_dist_nccl_spawn.py, which needs two devices.
 
 The children are started from this process as ordinary child processes (nothing is exec'ed in place of a process that has
-initialised the GPU); 1 + 3 processes on the card at most."""
+initialised the GPU); 1 + 4 processes on the card at most (the GPU boxes allow 6)."""
 import os
 import socket
 import subprocess
@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 4])
 def test_real_processes_on_one_gpu_match_one_domain(world):
     import dist_hip_worker
     with socket.socket() as s:
