@@ -42,6 +42,7 @@ def test_single_gpu_line_with_cpu_baseline_and_parity():
     assert cb['kind'] == 'port' and cb['cores'] == 1 and d['cpu_baseline_all_cores']['cores'] >= 1
     assert d['parity_rel_linf'] <= 1e-10 and d['parity']['steps'] == 3
     assert 'north_star_x_sweep' in d and d['north_star_x_sweep']['target_frac'] == 0.60
+    assert 'prewarm' in d and set(d['general_pack_sweeps_42B']) == {'sweep_axis0', 'sweep_axis1', 'sweep_axis2_contig'}
     # the other BASELINE.json configurations ride in the same line (after the timed region)
     al = d['also']
     assert set(al) == {'config2_256', 'config4_cyl', 'ellipsoid_64', 'robin_field_ellipsoid_64'}
