@@ -21,6 +21,13 @@ namespace adi {
 #define ADI_BUF_STRIDED 1   // unfused strided FAST kernels: buffer addressing for whole tiles (0: flat loads)
 #endif
 constexpr bool kBufStrided = ADI_BUF_STRIDED != 0;
+#ifndef ADI_LOAD_PRIO
+#define ADI_LOAD_PRIO 3     // s_setprio level of a wave while it issues its loads, back to 0 before its solver phase: waves that are
+#endif                      // loading go ahead of waves that are solving, so the memory pipe is fed earlier.  Round 4, alternating A/B
+                            // on one box (profiles/r04_r_load_prio_ab.txt): unfused strided FAST sweep (axis 1) 0.433 -> 0.419 ms
+                            // (-3 ... -5 %), cylindrical r / phi / z sweeps -5 / -3 / -1 % (step 0.141 -> 0.136 ms); NOT applied where
+                            // it measured neutral or worse: the fused kernel (+1 %), the GENERAL strided kernels (+1 ... +2 %), the
+                            // contiguous kernels (+-0)
 #ifndef ADI_FUSE_D
 #define ADI_FUSE_D 10    // rows of j-neighbour loads in flight per thread in the fused FAST kernels (512^3: 2 0.77 ms, 4 0.70, 8 0.68; with the results pinned in the loader 8 0.64-0.66, 10 0.63-0.65, 12 0.67, 16 0.90: spills)
 #endif

@@ -298,8 +298,14 @@ __global__ __launch_bounds__(1024) void k_cyl_phi_fast(
     const double f = fac[to], b0 = 1.0 + 2.0 * f;
 
     double d[M];
+#if ADI_LOAD_PRIO
+    __builtin_amdgcn_s_setprio(ADI_LOAD_PRIO);
+#endif
 #pragma unroll
     for (int r = 0; r < M; ++r) d[r] = in[base + (long)(r0 + r) * stride];
+#if ADI_LOAD_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // Sherman-Morrison split with gamma = -b0 (see k_cyl_strided): b'_0 = 2 b0, b'_{n-1} = b0 + f^2 / b0
     const bool firstseg = r0 == 0, lastseg = r0 + M == n;
     const double a0 = firstseg ? 0.0 : U.s, bf = firstseg ? 2.0 * b0 : U.bu;
@@ -351,7 +357,13 @@ __global__ __launch_bounds__(256) void k_cyl_z_fast(const double *in, double *ou
     const long base = (long)pi * sx + (long)(line - pi * (unsigned)lines_per_r0) * n + r0;
     const long wbase = __shfl(base, 0);                              // the wave's 64*M doubles are contiguous from lane 0's
     double d[M];
+#if ADI_LOAD_PRIO
+    __builtin_amdgcn_s_setprio(ADI_LOAD_PRIO);
+#endif
     coal_load<M>(in + wbase, strip, lane, d);
+#if ADI_LOAD_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const bool firstseg = li == 0, lastseg = r0 + M == n;
     const double a0 = firstseg ? 0.0 : U.s, bf = firstseg ? z.b0 : U.bu;
     if (firstseg) d[0] = d[0] + z.add0;                              // bottom closure, adi3d_cyl_phi_v3.py:271-283
@@ -413,6 +425,9 @@ __global__ __launch_bounds__(1024) void k_cyl_r_fast(
     CylRSegView T;
     T.p = rfac + (size_t)sg * RF_STRIDE;
     double d[M];
+#if ADI_LOAD_PRIO
+    __builtin_amdgcn_s_setprio(ADI_LOAD_PRIO);
+#endif
 #pragma unroll
     for (int r = 0; r < M; ++r) {
         const long p = base + (long)(r0 + r) * stride;
@@ -421,6 +436,9 @@ __global__ __launch_bounds__(1024) void k_cyl_r_fast(
         if (S != nullptr) v = v + s_scale * S[p];                            // R0 = Tn + dt*(S/(rho cp)), :339
         d[r] = v;
     }
+#if ADI_LOAD_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (r0 + M == n) d[M - 1] = d[M - 1] + add_last;                          // rhs_r[:, -1] += ..., :201
     // condensation of the right-hand side (the two recurrences of condense<M>, pivots from the table)
     double y = d[0], zb = d[MI - 1];

@@ -19,6 +19,7 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
 {
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x;
+    if constexpr (!FUSE && ADI_LOAD_PRIO != 0) __builtin_amdgcn_s_setprio(ADI_LOAD_PRIO);   // loading waves first (adi_cart_dev.hpp)
     long tile = xcd_chunk_tile(blockIdx.x, ntiles);
     if (FUSE && fz.kg > 0) tile = tile_jfast(tile, fz);
     if constexpr (!FUSE) {
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
             lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
                                                       active, d, f0, fS, dirS, kind, Lm);
     }
+    if constexpr (!FUSE && ADI_LOAD_PRIO != 0) __builtin_amdgcn_s_setprio(0);
     if (pad) { f0 = 0; fS = 0; dirS = false; }       // (the fused loader showed a padding thread segment 0's flags)
     if (!MIXED && kind >= SEG_TAIL) lane_fast = false;
     if (!__syncthreads_and(lane_fast)) {
