@@ -77,7 +77,6 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
             lane_fast = fast_segment_load<M, HAS_DIR>(in + tbase, flags + tbase, HAS_DIR ? dmask + tbase : dmask, g, voff, r0,
                                                       active, d, f0, fS, dirS, kind, Lm);
     }
-    if constexpr (!FUSE && ADI_LOAD_PRIO != 0) __builtin_amdgcn_s_setprio(0);
     if (pad) { f0 = 0; fS = 0; dirS = false; }       // (the fused loader showed a padding thread segment 0's flags)
     if (!MIXED && kind >= SEG_TAIL) lane_fast = false;
     if (!__syncthreads_and(lane_fast)) {
@@ -90,6 +89,9 @@ __global__ __launch_bounds__(512, FUSE ? ADI_FUSE_OCC : 1) void k_sweep_strided_
             corr_apply<M>(s, corr_weights(s, to), to, (voff + (unsigned)(ti * LINES)) * 8u, (unsigned)(g.stride * 8), d,
                           Lp * M == g.n && (ti + 1) * LINES <= g.n_inner);
     }
+    // back to normal priority for the solver phase -- AFTER the correction loads of a slab run (they are loads too: the
+    // corrected axis-1 sweep of the weak rehearsal 0.528 -> 0.490 ms with them inside the raised window)
+    if constexpr (!FUSE && ADI_LOAD_PRIO != 0) __builtin_amdgcn_s_setprio(0);
     double a0, b0, aS, bS, cS;
     fast_segment_ends<M, HAS_DIR, HAS_Q, (FC ? 1 : 2)>(coeff, dval, qf, g, base, r0, f0, fS, dirS, s, d, a0, b0, aS, bS, cS);
     if (r0 == 0) {
